@@ -1,0 +1,191 @@
+"""Host-side mirror of the reference's scene API over the C ABI.
+
+Names follow the reference: ``load_test_model`` = LoadTestModel* (TestModelH.h),
+``Scene.closest_hit`` = closestIntersection, ``Scene.any_hit`` = existsIntersection
+(intersections.h:7-13), ``Scene.render_accumulate`` = the pixel loop of Draw
+(main.cpp:121-139), ``Scene.resolve_argb`` = its tonemap loop (main.cpp:141-145).
+numpy arrays are host buffers (the library copies them); torch CUDA tensors are
+passed by device pointer and run on torch's current stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class MiptError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mipt error {code}: {msg}")
+        self.code = code
+
+
+def _check(rc):
+    if rc != abi.MIPT_OK:
+        raise MiptError(rc, abi.load_library().mipt_last_error().decode())
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _f32(a, shape_last=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape_last is not None and (a.ndim != 2 or a.shape[1] != shape_last):
+        raise ValueError(f"expected an (n, {shape_last}) float32 array, got {a.shape}")
+    return a
+
+
+def load_test_model(which):
+    """LoadTestModel / ...ColorBleeding / ...GlassCube / ...None as a TRIANGLE_DTYPE array."""
+    lib = abi.load_library()
+    tris = np.zeros(30, dtype=abi.TRIANGLE_DTYPE)
+    n = lib.mipt_load_test_model(which, _ptr(tris), 30)
+    if n < 0:
+        raise MiptError(n, lib.mipt_last_error().decode())
+    return tris[:n].copy()
+
+
+def default_camera(width):
+    cam = abi.MiptCamera()
+    abi.load_library().mipt_default_camera(C.byref(cam), width)
+    return cam
+
+
+def default_light(glass=False):
+    """reset_light (light.cpp:6-9); glass=True gives the light of the glass scenes (main.cpp:68-69)."""
+    light = abi.MiptLight()
+    abi.load_library().mipt_default_light(C.byref(light), 1 if glass else 0)
+    return light
+
+
+def default_params(width, height, **overrides):
+    p = abi.MiptParams()
+    abi.load_library().mipt_params_default(C.byref(p), width, height)
+    for k, v in overrides.items():
+        setattr(p, k, v)
+    return p
+
+
+def make_sphere(radius, center, color, material=abi.MAT_GLASS):
+    s = np.zeros(1, dtype=abi.SPHERE_DTYPE)
+    s["radius"] = radius
+    s["center"] = center
+    s["color"] = color
+    s["material"] = material
+    return s
+
+
+def path_key(seed, pixel, sample):
+    return abi.load_library().mipt_path_key(seed, pixel, sample)
+
+
+class Scene:
+    """Owns a MiptScene handle (device copy of the triangles / spheres)."""
+
+    def __init__(self, tris, spheres=None, device=0):
+        self._lib = abi.load_library()
+        tris = np.ascontiguousarray(tris, dtype=abi.TRIANGLE_DTYPE)
+        ns = 0 if spheres is None else len(spheres)
+        if ns:
+            spheres = np.ascontiguousarray(spheres, dtype=abi.SPHERE_DTYPE)
+        self.n_tris, self.n_spheres, self.device = len(tris), ns, device
+        h = C.c_void_p()
+        _check(self._lib.mipt_scene_create(_ptr(tris) if len(tris) else None, len(tris),
+                                           _ptr(spheres) if ns else None, ns, device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mipt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-pointer entry points (numpy) -------------------------------------------------
+    def closest_hit(self, origin4, dir4, want_position=True):
+        o, d = _f32(origin4, 4), _f32(dir4, 4)
+        if o.shape != d.shape:
+            raise ValueError("origin4 and dir4 differ in shape")
+        n = o.shape[0]
+        idx = np.full(n, -7, dtype=np.int32)
+        t = np.zeros(n, dtype=np.float32)
+        pos = np.zeros((n, 4), dtype=np.float32) if want_position else None
+        _check(self._lib.mipt_closest_hit(self._h, _ptr(o), _ptr(d), n, _ptr(idx), _ptr(t), _ptr(pos)))
+        return idx, t, pos
+
+    def any_hit(self, origin4, dir4, max_t):
+        o, d = _f32(origin4, 4), _f32(dir4, 4)
+        m = np.ascontiguousarray(max_t, dtype=np.float32)
+        n = o.shape[0]
+        if d.shape[0] != n or m.shape != (n,):
+            raise ValueError("origin4, dir4 and max_t differ in length")
+        occ = np.zeros(n, dtype=np.uint8)
+        _check(self._lib.mipt_any_hit(self._h, _ptr(o), _ptr(d), _ptr(m), n, _ptr(occ)))
+        return occ
+
+    def render_accumulate(self, cam, light, params, sample_begin, sample_count, accum=None):
+        W, H = params.width, params.height
+        if accum is None:
+            accum = np.zeros((W, H, 3), dtype=np.float32)
+        if accum.dtype != np.float32 or accum.shape != (W, H, 3) or not accum.flags.c_contiguous:
+            raise ValueError("accum must be a C-contiguous float32 (W, H, 3) array")
+        _check(self._lib.mipt_render_accumulate(self._h, C.byref(cam), C.byref(light), C.byref(params),
+                                                sample_begin, sample_count, _ptr(accum)))
+        return accum
+
+    def resolve_argb(self, accum, n_samples):
+        W, H = accum.shape[0], accum.shape[1]
+        out = np.zeros((H, W), dtype=np.uint32)
+        _check(self._lib.mipt_resolve_argb(self._h, _ptr(accum), W, H, n_samples, _ptr(out)))
+        return out
+
+    def trace_paths(self, cam, light, params, px, py, sample):
+        px = np.ascontiguousarray(px, dtype=np.int32)
+        py = np.ascontiguousarray(py, dtype=np.int32)
+        sample = np.ascontiguousarray(sample, dtype=np.uint32)
+        n = len(px)
+        rgb = np.zeros((n, 3), dtype=np.float32)
+        counts = np.zeros((n, 2), dtype=np.uint32)
+        _check(self._lib.mipt_trace_paths(self._h, C.byref(cam), C.byref(light), C.byref(params),
+                                          _ptr(px), _ptr(py), _ptr(sample), n, _ptr(rgb), _ptr(counts)))
+        return rgb, counts
+
+    def stats(self):
+        s = abi.MiptStats()
+        _check(self._lib.mipt_get_stats(self._h, C.byref(s)))
+        return s
+
+    # ---- device-pointer entry points (torch CUDA tensors, current stream) -------------------
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def closest_hit_dev(self, origin4, dir4, tri_idx, t, position4=None):
+        n = origin4.shape[0]
+        _check(self._lib.mipt_closest_hit_dev(self._h, origin4.data_ptr(), dir4.data_ptr(), n,
+                                              tri_idx.data_ptr(), t.data_ptr(),
+                                              position4.data_ptr() if position4 is not None else None,
+                                              self._stream()))
+
+    def any_hit_dev(self, origin4, dir4, max_t, occluded):
+        n = origin4.shape[0]
+        _check(self._lib.mipt_any_hit_dev(self._h, origin4.data_ptr(), dir4.data_ptr(),
+                                          max_t.data_ptr(), n, occluded.data_ptr(), self._stream()))
+
+    def render_accumulate_dev(self, cam, light, params, sample_begin, sample_count, accum):
+        """accum: float32 CUDA tensor of W*H*3 elements on the scene's device; samples are ADDED."""
+        if accum.numel() != params.width * params.height * 3 or not accum.is_contiguous():
+            raise ValueError("accum must be a contiguous float32 tensor of W*H*3 elements")
+        _check(self._lib.mipt_render_accumulate_dev(self._h, C.byref(cam), C.byref(light),
+                                                    C.byref(params), sample_begin, sample_count,
+                                                    accum.data_ptr(), self._stream()))
+
+    def resolve_argb_dev(self, accum, width, height, n_samples, screen):
+        _check(self._lib.mipt_resolve_argb_dev(self._h, accum.data_ptr(), width, height, n_samples,
+                                               screen.data_ptr(), self._stream()))

@@ -1,0 +1,217 @@
+/*
+ * mipt.h -- C ABI of the MI355X path-tracing hot path (libmipt.so).
+ *
+ * The library replaces, behind the reference raytracer's own scene model, the
+ * three seams of its unity build:
+ *     closestIntersection / existsIntersection   CW/raytracer/Source/intersections.h:7-13
+ *     trace (one path per pixel sample)           CW/raytracer/Source/pathtracer.h:4
+ *     Draw  (pixel loop + tonemap to the screen)  CW/raytracer/Source/definitions.h:61,
+ *                                                 body CW/raytracer/Source/main.cpp:110-146
+ * Everything crossing the boundary is plain C: pointers, sizes, POD structs.
+ * All entry points return MIPT_OK (0) or a negative MiptError; nothing throws.
+ * mipt_last_error() gives a thread-local message for the last failure.
+ *
+ * Threading: one MiptScene handle is externally synchronised (one host thread at
+ * a time); different handles may be used concurrently.
+ *
+ * Arithmetic contract: IEEE-754 binary32, every product and sum separately
+ * rounded (no FMA contraction), correctly rounded division and square root,
+ * subnormals kept -- the reference source evaluated under strict IEEE rules.
+ */
+#ifndef MIPT_H
+#define MIPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum MiptError {
+  MIPT_OK = 0,
+  MIPT_E_INVALID = -1,     /* bad argument (null pointer, size out of range, unsupported mode) */
+  MIPT_E_HIP = -2,         /* a HIP runtime call failed; mipt_last_error() names it */
+  MIPT_E_NOMEM = -3,       /* host or device allocation failed */
+  MIPT_E_UNSUPPORTED = -4  /* valid request this build cannot serve (e.g. oracle-only RNG mode) */
+} MiptError;
+
+/* Material of a primitive. The reference stores a `const char* type`
+ * (CW/raytracer/Source/material.h:5-11) and dispatches with strcmp
+ * (pathtracer.cpp:88,103-110); the host adapter maps the four strings to this
+ * enum. Any other string behaves as MIPT_MAT_NONE: the path ends with zero
+ * radiance at a non-terminal vertex and is shaded like diffuse at a terminal one. */
+typedef enum MiptMaterial {
+  MIPT_MAT_DIFFUSE = 0,
+  MIPT_MAT_MIRROR = 1,
+  MIPT_MAT_GLASS = 2,
+  MIPT_MAT_SPECULAR = 3,
+  MIPT_MAT_NONE = 4
+} MiptMaterial;
+
+/* Field-for-field `Triangle` (CW/raytracer/Source/TestModelH.h:11-49), 80 bytes. */
+typedef struct MiptTriangle {
+  float v0[4];
+  float v1[4];
+  float v2[4];
+  float color[3];
+  float normal[4];
+  uint32_t material; /* MiptMaterial */
+} MiptTriangle;
+
+/* `Sphere` (CW/raytracer/Source/sphere.h:9-16), 36 bytes. */
+typedef struct MiptSphere {
+  float radius;
+  float center[4];
+  float color[3];
+  uint32_t material; /* MiptMaterial */
+} MiptSphere;
+
+/* `Camera` (CW/raytracer/Source/definitions.h:16-23) without yaw/pitch, which the
+ * hot path never reads. Matrices are column-major like glm::mat4: rot[4*col + row]. */
+typedef struct MiptCamera {
+  float focal;
+  float pos[4];
+  float rot_x[16];
+  float rot_y[16];
+} MiptCamera;
+
+/* `Light` (CW/raytracer/Source/definitions.h:34-37). */
+typedef struct MiptLight {
+  float pos[4];
+  float color[3];
+} MiptLight;
+
+typedef enum MiptRngMode {
+  /* Per path: libstdc++ minstd_rand0 + generate_canonical<float,24>
+   * (the reference's `std::default_random_engine generator` /
+   * `uniform_real_distribution<float>(0,1)`, definitions.h:40-41), re-seeded for
+   * every (pixel, sample) from mipt_path_key(). Draw order inside a path is the
+   * reference's (g++ right-to-left argument evaluation at pathtracer.cpp:8). */
+  MIPT_RNG_MINSTD_PATH = 0,
+  /* Fully counter-based: draw k of path (pixel, sample) is a hash of
+   * (seed, pixel, sample, k). No sequential state at all. */
+  MIPT_RNG_COUNTER = 1,
+  /* One engine shared by all pixels in x-major loop order, default seed 1: the
+   * reference's single-threaded behaviour. Sequential by construction, so only
+   * the CPU oracle implements it; the GPU library returns MIPT_E_UNSUPPORTED. */
+  MIPT_RNG_MINSTD_GLOBAL = 2
+} MiptRngMode;
+
+enum {
+  MIPT_FLAG_STATS = 1u /* count rays / triangle tests / gate passes (slower kernel variant) */
+};
+
+#define MIPT_MAX_DEPTH_LIMIT 16
+
+/* Compile-time constants of the reference (definitions.h:43-55) as run-time
+ * parameters; mipt_params_default() fills in the reference's values. */
+typedef struct MiptParams {
+  int32_t width;         /* SCREEN_WIDTH  */
+  int32_t height;        /* SCREEN_HEIGHT */
+  int32_t max_depth;     /* MAX_DEPTH 10; 0..MIPT_MAX_DEPTH_LIMIT */
+  float rr_prob;         /* RUSSIAN_ROULETTE_FACTOR 0.15f */
+  float diffuse_weight;  /* DIFFUSE_MAGIC_NUMBER 0.5f */
+  float glass_weight;    /* GLASS_MAGIC_NUMBER 1.15f */
+  float ior_glass;       /* GLASS_INDEX_OF_REFRACTION 1.512f */
+  float ior_air;         /* AIR_INDEX_OF_REFRACTION 1.000f */
+  uint32_t rng_mode;     /* MiptRngMode */
+  uint32_t seed;
+  /* Homogeneous fog. Not in the reference source (its README lists it as a
+   * feature only); sigma_t == 0 disables it and leaves the RNG stream untouched. */
+  float fog_sigma_t;
+  float fog_albedo;
+  uint32_t flags;        /* MIPT_FLAG_* */
+} MiptParams;
+
+typedef struct MiptStats {
+  uint64_t paths;          /* pixel samples traced */
+  uint64_t closest_rays;   /* closestIntersection calls */
+  uint64_t shadow_rays;    /* existsIntersection calls */
+  uint64_t tri_tests;      /* determinant-ratio gate evaluations */
+  uint64_t gate_passes;    /* tests that went on to the inverse path */
+  uint64_t sphere_tests;
+  uint64_t fog_events;     /* scattering events in the medium */
+  uint64_t diffuse_bounces; /* bounceDiffuse calls */
+  uint64_t mirror_bounces;  /* bounceMirror calls */
+  uint64_t glass_bounces;   /* bounceGlass calls */
+  double kernel_ms;        /* device time of the last render call's path kernel */
+} MiptStats;
+
+typedef struct MiptScene MiptScene; /* opaque */
+
+void mipt_params_default(MiptParams* p, int width, int height);
+const char* mipt_last_error(void);
+/* "mipt <version> gfx950 hip" */
+const char* mipt_version(void);
+
+/* Copies the host scene (main.cpp:46-47 `vector<Triangle> triangles`,
+ * `vector<Sphere> spheres`, immutable after load) to `device` and prepares the
+ * per-triangle edge/cofactor table the kernels read. The caller keeps its arrays. */
+int mipt_scene_create(const MiptTriangle* tris, size_t n_tris,
+                      const MiptSphere* spheres, size_t n_spheres,
+                      int device, MiptScene** out);
+void mipt_scene_destroy(MiptScene* scene);
+
+/* Batch closestIntersection (intersections.cpp:6-55). Host pointers.
+ * tri_idx[i] = -1 on a miss, the triangle index, or n_tris + s for sphere s;
+ * t[i] = Intersection::distance (|x.x| of the inverse path; untouched on a miss);
+ * position4 (nullable) = Intersection::position. Bit-exact contract. */
+int mipt_closest_hit(MiptScene* scene, const float* origin4, const float* dir4,
+                     size_t n_rays, int32_t* tri_idx, float* t, float* position4);
+
+/* Batch existsIntersection (intersections.cpp:57-85): triangles only, gate
+ * t <= max_t[i], barycentric bound <= 1. occluded[i] is 0 or 1. */
+int mipt_any_hit(MiptScene* scene, const float* origin4, const float* dir4,
+                 const float* max_t, size_t n_rays, uint8_t* occluded);
+
+/* Replaces the pixel loop of Draw (main.cpp:121-139) for samples
+ * [sample_begin, sample_begin + sample_count) of every pixel, and ADDS the
+ * radiance sums into the caller's accumulation buffer: accum_rgb is a host
+ * float[width*height*3], pixel (x, y) at ((x*height)+y)*3 -- x-major, like the
+ * reference's `vec3** pixels` columns (main.cpp:55-57). */
+int mipt_render_accumulate(MiptScene* scene, const MiptCamera* cam, const MiptLight* light,
+                           const MiptParams* params, uint32_t sample_begin,
+                           uint32_t sample_count, float* accum_rgb);
+
+/* The tonemap loop of Draw (main.cpp:141-145) with PutPixelSDL
+ * (SDLauxiliary.h:149-161): c = accum/(N*(1/(2*3.1415f))), clamp(255c, 0, 255),
+ * screen_buffer[y*width + x] = (128<<24) + (r<<16) + (g<<8) + b. Host pointers. */
+int mipt_resolve_argb(MiptScene* scene, const float* accum_rgb, int width, int height,
+                      uint32_t n_samples, uint32_t* screen_buffer);
+
+/* Radiance of individual paths, for matched-stream parity checks: path i is
+ * pixel (px[i], py[i]), sample index sample[i]; rgb gets 3 floats per path,
+ * ray_counts (nullable) gets {closest calls, shadow calls} per path. Host pointers. */
+int mipt_trace_paths(MiptScene* scene, const MiptCamera* cam, const MiptLight* light,
+                     const MiptParams* params, const int32_t* px, const int32_t* py,
+                     const uint32_t* sample, size_t n_paths, float* rgb, uint32_t* ray_counts);
+
+/* Device-pointer variants: every buffer already lives in the memory of the scene's
+ * GPU, `stream` is a hipStream_t (NULL = default stream). Launch is asynchronous;
+ * the caller synchronises the stream. Used by the one-process-per-GPU driver so
+ * that the accumulation buffer can be handed to RCCL without a host round trip. */
+int mipt_closest_hit_dev(MiptScene* scene, const float* d_origin4, const float* d_dir4,
+                         size_t n_rays, int32_t* d_tri_idx, float* d_t, float* d_position4,
+                         void* stream);
+int mipt_any_hit_dev(MiptScene* scene, const float* d_origin4, const float* d_dir4,
+                     const float* d_max_t, size_t n_rays, uint8_t* d_occluded, void* stream);
+int mipt_render_accumulate_dev(MiptScene* scene, const MiptCamera* cam, const MiptLight* light,
+                               const MiptParams* params, uint32_t sample_begin,
+                               uint32_t sample_count, float* d_accum_rgb, void* stream);
+int mipt_resolve_argb_dev(MiptScene* scene, const float* d_accum_rgb, int width, int height,
+                          uint32_t n_samples, uint32_t* d_screen_buffer, void* stream);
+
+/* Counters of the most recent render / trace call made with MIPT_FLAG_STATS, and
+ * the device time of its path kernel (measured with HIP events on the launch
+ * stream; synchronises that stream). */
+int mipt_get_stats(MiptScene* scene, MiptStats* out);
+
+/* The (seed, pixel, sample) -> 32-bit key shared by both per-path RNG modes.
+ * pixel = x*height + y. Exposed so that hosts and tests can reproduce streams. */
+uint32_t mipt_path_key(uint32_t seed, uint32_t pixel, uint32_t sample);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPT_H */
