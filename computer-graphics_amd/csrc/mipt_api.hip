@@ -1,0 +1,481 @@
+// mipt_api.hip -- the C ABI of include/mipt.h over the kernels of mipt_kernels.hpp.
+// Host side: validates shapes before any launch, owns the scene's device memory, never throws.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mipt_kernels.hpp"
+
+using namespace mipt;
+
+// ---------------------------------------------------------------------------------------
+// errors
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(call)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(e_ == hipErrorOutOfMemory ? MIPT_E_NOMEM : MIPT_E_HIP, "%s failed: %s", #call, \
+                  hipGetErrorString(e_));                                                       \
+  } while (0)
+
+extern "C" const char* mipt_last_error(void) { return g_err; }
+extern "C" const char* mipt_version(void) { return "mipt 0.1 gfx950 hip"; }
+
+// ---------------------------------------------------------------------------------------
+// scene
+
+struct MiptScene {
+  int device = 0;
+  DeviceScene d{};
+  TriRec* d_tris = nullptr;
+  ShadeRec* d_shade = nullptr;
+  SphereRec* d_spheres = nullptr;
+  unsigned long long* d_stats = nullptr;
+  float* d_partial = nullptr;
+  size_t partial_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  bool stats_valid = false;
+  uint64_t last_paths = 0;
+};
+
+static void scene_free(MiptScene* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->d_tris) (void)hipFree(s->d_tris);
+  if (s->d_shade) (void)hipFree(s->d_shade);
+  if (s->d_spheres) (void)hipFree(s->d_spheres);
+  if (s->d_stats) (void)hipFree(s->d_stats);
+  if (s->d_partial) (void)hipFree(s->d_partial);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  delete s;
+}
+
+extern "C" void mipt_scene_destroy(MiptScene* s) { scene_free(s); }
+
+static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
+                             size_t n_spheres, int device, MiptScene* s) {
+  s->device = device;
+  HIP_TRY(hipSetDevice(device));
+  std::vector<TriRec> tr(n_tris ? n_tris : 1);
+  std::vector<ShadeRec> sh(n_tris + n_spheres ? n_tris + n_spheres : 1);
+  std::vector<SphereRec> sp(n_spheres ? n_spheres : 1);
+  for (size_t i = 0; i < n_tris; ++i) {
+    const MiptTriangle& t = tris[i];
+    TriRec& r = tr[i];
+    memset(&r, 0, sizeof r);
+    r.v0x = t.v0[0]; r.v0y = t.v0[1]; r.v0z = t.v0[2]; r.v0w = t.v0[3];
+    // intersections.cpp:17-18; plain float subtraction, same on host and device
+    volatile float e1x = t.v1[0] - t.v0[0], e1y = t.v1[1] - t.v0[1], e1z = t.v1[2] - t.v0[2];
+    volatile float e2x = t.v2[0] - t.v0[0], e2y = t.v2[1] - t.v0[1], e2z = t.v2[2] - t.v0[2];
+    r.e1x = e1x; r.e1y = e1y; r.e1z = e1z;
+    r.e2x = e2x; r.e2y = e2y; r.e2z = e2z;
+    // cofactors; each product is stored before the subtraction so that no FMA can form
+    volatile float a0 = e1y * e2z, b0 = e2y * e1z;
+    volatile float a1 = e1x * e2z, b1 = e2x * e1z;
+    volatile float a2 = e1x * e2y, b2 = e2x * e1y;
+    r.c0 = a0 - b0; r.c1 = a1 - b1; r.c2 = a2 - b2;
+    ShadeRec& q = sh[i];
+    q.nx = t.normal[0]; q.ny = t.normal[1]; q.nz = t.normal[2]; q.nw = t.normal[3];
+    q.r = t.color[0]; q.g = t.color[1]; q.b = t.color[2];
+    q.material = t.material;
+  }
+  for (size_t j = 0; j < n_spheres; ++j) {
+    const MiptSphere& u = spheres[j];
+    SphereRec& r = sp[j];
+    memset(&r, 0, sizeof r);
+    r.cx = u.center[0]; r.cy = u.center[1]; r.cz = u.center[2]; r.cw = u.center[3];
+    r.radius = u.radius; r.r = u.color[0]; r.g = u.color[1]; r.b = u.color[2];
+    r.material = u.material;
+    ShadeRec& q = sh[n_tris + j];
+    memset(&q, 0, sizeof q);
+    q.r = u.color[0]; q.g = u.color[1]; q.b = u.color[2];
+    q.material = u.material;
+  }
+  HIP_TRY(hipMalloc(&s->d_tris, tr.size() * sizeof(TriRec)));
+  HIP_TRY(hipMalloc(&s->d_shade, sh.size() * sizeof(ShadeRec)));
+  HIP_TRY(hipMalloc(&s->d_spheres, sp.size() * sizeof(SphereRec)));
+  HIP_TRY(hipMalloc(&s->d_stats, ST_COUNT * sizeof(unsigned long long)));
+  HIP_TRY(hipMemcpy(s->d_tris, tr.data(), tr.size() * sizeof(TriRec), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->d_shade, sh.data(), sh.size() * sizeof(ShadeRec), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->d_spheres, sp.data(), sp.size() * sizeof(SphereRec), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(s->d_stats, 0, ST_COUNT * sizeof(unsigned long long)));
+  HIP_TRY(hipEventCreate(&s->ev0));
+  HIP_TRY(hipEventCreate(&s->ev1));
+  s->d.tris = s->d_tris;
+  s->d.shade = s->d_shade;
+  s->d.spheres = s->d_spheres;
+  s->d.n_tris = (int)n_tris;
+  s->d.n_spheres = (int)n_spheres;
+  return MIPT_OK;
+}
+
+extern "C" int mipt_scene_create(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
+                                 size_t n_spheres, int device, MiptScene** out) {
+  if (!out) return fail(MIPT_E_INVALID, "mipt_scene_create: out is null");
+  *out = nullptr;
+  if ((n_tris && !tris) || (n_spheres && !spheres))
+    return fail(MIPT_E_INVALID, "mipt_scene_create: null primitive array with non-zero count");
+  if (n_tris > (size_t)1 << 24 || n_spheres > 4096)
+    return fail(MIPT_E_INVALID, "mipt_scene_create: too many primitives (%zu triangles, %zu spheres)",
+                n_tris, n_spheres);
+  for (size_t i = 0; i < n_tris; ++i)
+    if (tris[i].material > MIPT_MAT_NONE)
+      return fail(MIPT_E_INVALID, "mipt_scene_create: triangle %zu has material code %u", i, tris[i].material);
+  for (size_t j = 0; j < n_spheres; ++j)
+    if (spheres[j].material > MIPT_MAT_NONE)
+      return fail(MIPT_E_INVALID, "mipt_scene_create: sphere %zu has material code %u", j, spheres[j].material);
+  int n_dev = 0;
+  HIP_TRY(hipGetDeviceCount(&n_dev));
+  if (device < 0 || device >= n_dev)
+    return fail(MIPT_E_INVALID, "mipt_scene_create: device %d out of range (%d devices)", device, n_dev);
+  MiptScene* s = new (std::nothrow) MiptScene();
+  if (!s) return fail(MIPT_E_NOMEM, "mipt_scene_create: host allocation failed");
+  int rc = scene_create_impl(tris, n_tris, spheres, n_spheres, device, s);
+  if (rc != MIPT_OK) { scene_free(s); return rc; }
+  *out = s;
+  return MIPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// batch queries
+
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+extern "C" int mipt_closest_hit_dev(MiptScene* s, const float* d_origin4, const float* d_dir4, size_t n_rays,
+                                    int32_t* d_tri_idx, float* d_t, float* d_position4, void* stream) {
+  if (!s) return fail(MIPT_E_INVALID, "mipt_closest_hit: scene is null");
+  if (n_rays == 0) return MIPT_OK;
+  if (!d_origin4 || !d_dir4 || !d_tri_idx || !d_t) return fail(MIPT_E_INVALID, "mipt_closest_hit: null buffer");
+  if (n_rays > ((size_t)1 << 31) * BLOCK) return fail(MIPT_E_INVALID, "mipt_closest_hit: too many rays");
+  HIP_TRY(hipSetDevice(s->device));
+  hipLaunchKernelGGL(k_closest_hit, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
+                     (const float4*)d_origin4, (const float4*)d_dir4, n_rays, d_tri_idx, d_t,
+                     (float4*)d_position4);
+  HIP_TRY(hipGetLastError());
+  return MIPT_OK;
+}
+
+extern "C" int mipt_any_hit_dev(MiptScene* s, const float* d_origin4, const float* d_dir4, const float* d_max_t,
+                                size_t n_rays, uint8_t* d_occluded, void* stream) {
+  if (!s) return fail(MIPT_E_INVALID, "mipt_any_hit: scene is null");
+  if (n_rays == 0) return MIPT_OK;
+  if (!d_origin4 || !d_dir4 || !d_max_t || !d_occluded) return fail(MIPT_E_INVALID, "mipt_any_hit: null buffer");
+  if (n_rays > ((size_t)1 << 31) * BLOCK) return fail(MIPT_E_INVALID, "mipt_any_hit: too many rays");
+  HIP_TRY(hipSetDevice(s->device));
+  hipLaunchKernelGGL(k_any_hit, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
+                     (const float4*)d_origin4, (const float4*)d_dir4, d_max_t, n_rays, d_occluded);
+  HIP_TRY(hipGetLastError());
+  return MIPT_OK;
+}
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  template <typename T> T* as() { return static_cast<T*>(p); }
+};
+
+extern "C" int mipt_closest_hit(MiptScene* s, const float* origin4, const float* dir4, size_t n_rays,
+                                int32_t* tri_idx, float* t, float* position4) {
+  if (!s) return fail(MIPT_E_INVALID, "mipt_closest_hit: scene is null");
+  if (n_rays == 0) return MIPT_OK;
+  if (!origin4 || !dir4 || !tri_idx || !t) return fail(MIPT_E_INVALID, "mipt_closest_hit: null buffer");
+  HIP_TRY(hipSetDevice(s->device));
+  DevBuf o, d, idx, tt, pos;
+  HIP_TRY(o.alloc(n_rays * 16)); HIP_TRY(d.alloc(n_rays * 16));
+  HIP_TRY(idx.alloc(n_rays * 4)); HIP_TRY(tt.alloc(n_rays * 4));
+  if (position4) HIP_TRY(pos.alloc(n_rays * 16));
+  HIP_TRY(hipMemcpy(o.p, origin4, n_rays * 16, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d.p, dir4, n_rays * 16, hipMemcpyHostToDevice));
+  // outputs keep the caller's values where the kernel does not write (t / position on a miss)
+  HIP_TRY(hipMemcpy(tt.p, t, n_rays * 4, hipMemcpyHostToDevice));
+  if (position4) HIP_TRY(hipMemcpy(pos.p, position4, n_rays * 16, hipMemcpyHostToDevice));
+  int rc = mipt_closest_hit_dev(s, o.as<float>(), d.as<float>(), n_rays, idx.as<int32_t>(), tt.as<float>(),
+                                position4 ? pos.as<float>() : nullptr, nullptr);
+  if (rc != MIPT_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(tri_idx, idx.p, n_rays * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(t, tt.p, n_rays * 4, hipMemcpyDeviceToHost));
+  if (position4) HIP_TRY(hipMemcpy(position4, pos.p, n_rays * 16, hipMemcpyDeviceToHost));
+  return MIPT_OK;
+}
+
+extern "C" int mipt_any_hit(MiptScene* s, const float* origin4, const float* dir4, const float* max_t,
+                            size_t n_rays, uint8_t* occluded) {
+  if (!s) return fail(MIPT_E_INVALID, "mipt_any_hit: scene is null");
+  if (n_rays == 0) return MIPT_OK;
+  if (!origin4 || !dir4 || !max_t || !occluded) return fail(MIPT_E_INVALID, "mipt_any_hit: null buffer");
+  HIP_TRY(hipSetDevice(s->device));
+  DevBuf o, d, m, occ;
+  HIP_TRY(o.alloc(n_rays * 16)); HIP_TRY(d.alloc(n_rays * 16));
+  HIP_TRY(m.alloc(n_rays * 4)); HIP_TRY(occ.alloc(n_rays));
+  HIP_TRY(hipMemcpy(o.p, origin4, n_rays * 16, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d.p, dir4, n_rays * 16, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m.p, max_t, n_rays * 4, hipMemcpyHostToDevice));
+  int rc = mipt_any_hit_dev(s, o.as<float>(), d.as<float>(), m.as<float>(), n_rays, occ.as<uint8_t>(), nullptr);
+  if (rc != MIPT_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(occluded, occ.p, n_rays, hipMemcpyDeviceToHost));
+  return MIPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// path kernel launch
+
+static int check_params(const char* who, const MiptCamera* cam, const MiptLight* light, const MiptParams* p) {
+  if (!cam || !light || !p) return fail(MIPT_E_INVALID, "%s: null camera / light / params", who);
+  if (p->width <= 0 || p->height <= 0 || p->width > 32768 || p->height > 32768)
+    return fail(MIPT_E_INVALID, "%s: image size %d x %d out of range", who, p->width, p->height);
+  if (p->max_depth < 0 || p->max_depth > MIPT_MAX_DEPTH_LIMIT)
+    return fail(MIPT_E_INVALID, "%s: max_depth %d outside 0..%d", who, p->max_depth, MIPT_MAX_DEPTH_LIMIT);
+  if (p->rng_mode == MIPT_RNG_MINSTD_GLOBAL)
+    return fail(MIPT_E_UNSUPPORTED,
+                "%s: MIPT_RNG_MINSTD_GLOBAL is one sequential stream over all pixels; only the CPU oracle has it", who);
+  if (p->rng_mode != MIPT_RNG_MINSTD_PATH && p->rng_mode != MIPT_RNG_COUNTER)
+    return fail(MIPT_E_INVALID, "%s: unknown rng_mode %u", who, p->rng_mode);
+  if (!(p->fog_sigma_t >= 0.f)) return fail(MIPT_E_INVALID, "%s: fog_sigma_t must be >= 0", who);
+  return MIPT_OK;
+}
+
+// mat4 * mat4 in GLM's order (type_mat4x4.inl:722-727), each operation rounded to float
+static void mat4_mul(const float a[16], const float b[16], float out[16]) {
+  for (int j = 0; j < 4; ++j)
+    for (int k = 0; k < 4; ++k) {
+      volatile float s0 = a[0 * 4 + k] * b[j * 4 + 0];
+      volatile float s1 = a[1 * 4 + k] * b[j * 4 + 1];
+      volatile float s2 = a[2 * 4 + k] * b[j * 4 + 2];
+      volatile float s3 = a[3 * 4 + k] * b[j * 4 + 3];
+      volatile float t0 = s0 + s1;
+      volatile float t1 = t0 + s2;
+      out[j * 4 + k] = t1 + s3;
+    }
+}
+
+static void fill_args(PathArgs& a, const MiptScene* s, const MiptCamera* cam, const MiptLight* light,
+                      const MiptParams* p) {
+  memset(&a, 0, sizeof a);
+  a.sc = s->d;
+  mat4_mul(cam->rot_x, cam->rot_y, a.M);
+  memcpy(a.cam_pos, cam->pos, sizeof a.cam_pos);
+  a.focal = cam->focal;
+  memcpy(a.light_pos, light->pos, sizeof a.light_pos);
+  memcpy(a.light_col, light->color, sizeof a.light_col);
+  a.p = *p;
+  a.stats = s->d_stats;
+}
+
+static size_t stack_bytes(const MiptScene* s, const MiptParams* p) {
+  size_t per_level = (size_t)BLOCK * 4 * (s->d.n_spheres > 0 ? 5 : 1);
+  return per_level * (size_t)p->max_depth;
+}
+
+template <bool LIST>
+static void launch_paths(const PathArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  const bool stats = (a.p.flags & MIPT_FLAG_STATS) != 0;
+  const bool counter = a.p.rng_mode == MIPT_RNG_COUNTER;
+  if (counter) {
+    if (stats) hipLaunchKernelGGL((k_paths<MIPT_RNG_COUNTER, true, LIST>), grid, dim3(BLOCK), lds, st, a);
+    else hipLaunchKernelGGL((k_paths<MIPT_RNG_COUNTER, false, LIST>), grid, dim3(BLOCK), lds, st, a);
+  } else {
+    if (stats) hipLaunchKernelGGL((k_paths<MIPT_RNG_MINSTD_PATH, true, LIST>), grid, dim3(BLOCK), lds, st, a);
+    else hipLaunchKernelGGL((k_paths<MIPT_RNG_MINSTD_PATH, false, LIST>), grid, dim3(BLOCK), lds, st, a);
+  }
+}
+
+extern "C" int mipt_render_accumulate_dev(MiptScene* s, const MiptCamera* cam, const MiptLight* light,
+                                          const MiptParams* p, uint32_t sample_begin, uint32_t sample_count,
+                                          float* d_accum_rgb, void* stream) {
+  if (!s) return fail(MIPT_E_INVALID, "mipt_render_accumulate: scene is null");
+  int rc = check_params("mipt_render_accumulate", cam, light, p);
+  if (rc != MIPT_OK) return rc;
+  if (!d_accum_rgb) return fail(MIPT_E_INVALID, "mipt_render_accumulate: accumulation buffer is null");
+  if (sample_count == 0) return MIPT_OK;
+  if (sample_begin + sample_count < sample_begin)
+    return fail(MIPT_E_INVALID, "mipt_render_accumulate: sample range wraps around 2^32");
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t st = (hipStream_t)stream;
+
+  const uint32_t tiles_x = (uint32_t)((p->width + TILE_X - 1) / TILE_X);
+  const uint32_t tiles_y = (uint32_t)((p->height + TILE_Y - 1) / TILE_Y);
+  const uint32_t pixel_blocks = tiles_x * tiles_y;
+  // many more blocks than the chip has slots, but at least 32 samples per chunk
+  uint32_t n_chunks = (65536u + pixel_blocks - 1) / pixel_blocks;
+  uint32_t max_chunks = sample_count / 32u;
+  if (max_chunks < 1) max_chunks = 1;
+  if (n_chunks > max_chunks) n_chunks = max_chunks;
+  if (n_chunks > 65535u) n_chunks = 65535u;
+  const uint32_t chunk = (sample_count + n_chunks - 1) / n_chunks;
+  n_chunks = (sample_count + chunk - 1) / chunk;
+
+  const size_t n_img = (size_t)p->width * p->height * 3;
+  const size_t need = n_img * sizeof(float) * n_chunks;
+  if (need > s->partial_bytes) {
+    // the scratch image stack is kept with the scene and only ever grows
+    HIP_TRY(hipStreamSynchronize(st));
+    if (s->d_partial) { (void)hipFree(s->d_partial); s->d_partial = nullptr; s->partial_bytes = 0; }
+    HIP_TRY(hipMalloc(&s->d_partial, need));
+    s->partial_bytes = need;
+  }
+
+  PathArgs a;
+  fill_args(a, s, cam, light, p);
+  a.sample_begin = sample_begin;
+  a.sample_count = sample_count;
+  a.chunk = chunk;
+  a.tiles_x = tiles_x;
+  a.partial = s->d_partial;
+  const bool stats = (p->flags & MIPT_FLAG_STATS) != 0;
+  if (stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, ST_COUNT * sizeof(unsigned long long), st));
+  HIP_TRY(hipEventRecord(s->ev0, st));
+  launch_paths<false>(a, dim3(pixel_blocks, n_chunks), stack_bytes(s, p), st);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->ev1, st));
+  hipLaunchKernelGGL(k_reduce_chunks, dim3(grid_for(n_img)), dim3(BLOCK), 0, st, s->d_partial, n_chunks, n_img,
+                     d_accum_rgb);
+  HIP_TRY(hipGetLastError());
+  s->timed = true;
+  s->stats_valid = stats;
+  s->last_paths = (uint64_t)p->width * p->height * sample_count;
+  return MIPT_OK;
+}
+
+extern "C" int mipt_render_accumulate(MiptScene* s, const MiptCamera* cam, const MiptLight* light,
+                                      const MiptParams* p, uint32_t sample_begin, uint32_t sample_count,
+                                      float* accum_rgb) {
+  if (!s) return fail(MIPT_E_INVALID, "mipt_render_accumulate: scene is null");
+  int rc = check_params("mipt_render_accumulate", cam, light, p);
+  if (rc != MIPT_OK) return rc;
+  if (!accum_rgb) return fail(MIPT_E_INVALID, "mipt_render_accumulate: accumulation buffer is null");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t bytes = (size_t)p->width * p->height * 3 * sizeof(float);
+  DevBuf acc;
+  HIP_TRY(acc.alloc(bytes));
+  HIP_TRY(hipMemcpy(acc.p, accum_rgb, bytes, hipMemcpyHostToDevice));
+  rc = mipt_render_accumulate_dev(s, cam, light, p, sample_begin, sample_count, acc.as<float>(), nullptr);
+  if (rc != MIPT_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(accum_rgb, acc.p, bytes, hipMemcpyDeviceToHost));
+  return MIPT_OK;
+}
+
+extern "C" int mipt_trace_paths(MiptScene* s, const MiptCamera* cam, const MiptLight* light, const MiptParams* p,
+                                const int32_t* px, const int32_t* py, const uint32_t* sample, size_t n_paths,
+                                float* rgb, uint32_t* ray_counts) {
+  if (!s) return fail(MIPT_E_INVALID, "mipt_trace_paths: scene is null");
+  int rc = check_params("mipt_trace_paths", cam, light, p);
+  if (rc != MIPT_OK) return rc;
+  if (n_paths == 0) return MIPT_OK;
+  if (!px || !py || !sample || !rgb) return fail(MIPT_E_INVALID, "mipt_trace_paths: null buffer");
+  if (n_paths > 0x7FFFFFFFu) return fail(MIPT_E_INVALID, "mipt_trace_paths: too many paths");
+  for (size_t i = 0; i < n_paths; ++i)
+    if (px[i] < 0 || px[i] >= p->width || py[i] < 0 || py[i] >= p->height)
+      return fail(MIPT_E_INVALID, "mipt_trace_paths: path %zu pixel (%d, %d) outside the image", i, px[i], py[i]);
+  HIP_TRY(hipSetDevice(s->device));
+  DevBuf dx, dy, ds, drgb, dcnt;
+  HIP_TRY(dx.alloc(n_paths * 4)); HIP_TRY(dy.alloc(n_paths * 4)); HIP_TRY(ds.alloc(n_paths * 4));
+  HIP_TRY(drgb.alloc(n_paths * 12)); HIP_TRY(dcnt.alloc(n_paths * 8));
+  HIP_TRY(hipMemcpy(dx.p, px, n_paths * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dy.p, py, n_paths * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ds.p, sample, n_paths * 4, hipMemcpyHostToDevice));
+  PathArgs a;
+  fill_args(a, s, cam, light, p);
+  a.px = dx.as<int32_t>(); a.py = dy.as<int32_t>(); a.samp = ds.as<uint32_t>();
+  a.n_paths = (uint32_t)n_paths;
+  a.rgb = drgb.as<float>();
+  a.counts = dcnt.as<uint32_t>();
+  const bool stats = (p->flags & MIPT_FLAG_STATS) != 0;
+  if (stats) HIP_TRY(hipMemset(s->d_stats, 0, ST_COUNT * sizeof(unsigned long long)));
+  HIP_TRY(hipEventRecord(s->ev0, nullptr));
+  launch_paths<true>(a, dim3(grid_for(n_paths)), stack_bytes(s, p), nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->ev1, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  s->timed = true;
+  s->stats_valid = stats;
+  s->last_paths = n_paths;
+  HIP_TRY(hipMemcpy(rgb, drgb.p, n_paths * 12, hipMemcpyDeviceToHost));
+  if (ray_counts) HIP_TRY(hipMemcpy(ray_counts, dcnt.p, n_paths * 8, hipMemcpyDeviceToHost));
+  return MIPT_OK;
+}
+
+extern "C" int mipt_get_stats(MiptScene* s, MiptStats* out) {
+  if (!s || !out) return fail(MIPT_E_INVALID, "mipt_get_stats: null argument");
+  memset(out, 0, sizeof *out);
+  if (!s->timed) return fail(MIPT_E_INVALID, "mipt_get_stats: no render or trace call has run on this scene");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventSynchronize(s->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+  out->kernel_ms = ms;
+  out->paths = s->last_paths;
+  if (s->stats_valid) {
+    unsigned long long h[ST_COUNT];
+    HIP_TRY(hipMemcpy(h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    out->paths = h[ST_PATHS];
+    out->closest_rays = h[ST_CLOSEST]; out->shadow_rays = h[ST_SHADOW];
+    out->tri_tests = h[ST_TESTS]; out->gate_passes = h[ST_GATE];
+    out->sphere_tests = h[ST_SPHERE]; out->fog_events = h[ST_FOG];
+    out->diffuse_bounces = h[ST_DIFFUSE]; out->mirror_bounces = h[ST_MIRROR]; out->glass_bounces = h[ST_GLASS];
+  }
+  return MIPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// resolve
+
+extern "C" int mipt_resolve_argb_dev(MiptScene* s, const float* d_accum_rgb, int width, int height,
+                                     uint32_t n_samples, uint32_t* d_screen, void* stream) {
+  if (!s) return fail(MIPT_E_INVALID, "mipt_resolve_argb: scene is null");
+  if (!d_accum_rgb || !d_screen) return fail(MIPT_E_INVALID, "mipt_resolve_argb: null buffer");
+  if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
+    return fail(MIPT_E_INVALID, "mipt_resolve_argb: image size %d x %d out of range", width, height);
+  if (n_samples > 0x7FFFFFFFu) return fail(MIPT_E_INVALID, "mipt_resolve_argb: sample count exceeds int range");
+  HIP_TRY(hipSetDevice(s->device));
+  hipLaunchKernelGGL(k_resolve_argb, dim3(grid_for((size_t)width * height)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     d_accum_rgb, width, height, n_samples, d_screen);
+  HIP_TRY(hipGetLastError());
+  return MIPT_OK;
+}
+
+extern "C" int mipt_resolve_argb(MiptScene* s, const float* accum_rgb, int width, int height, uint32_t n_samples,
+                                 uint32_t* screen_buffer) {
+  if (!s) return fail(MIPT_E_INVALID, "mipt_resolve_argb: scene is null");
+  if (!accum_rgb || !screen_buffer) return fail(MIPT_E_INVALID, "mipt_resolve_argb: null buffer");
+  if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
+    return fail(MIPT_E_INVALID, "mipt_resolve_argb: image size %d x %d out of range", width, height);
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t n = (size_t)width * height;
+  DevBuf acc, scr;
+  HIP_TRY(acc.alloc(n * 12)); HIP_TRY(scr.alloc(n * 4));
+  HIP_TRY(hipMemcpy(acc.p, accum_rgb, n * 12, hipMemcpyHostToDevice));
+  int rc = mipt_resolve_argb_dev(s, acc.as<float>(), width, height, n_samples, scr.as<uint32_t>(), nullptr);
+  if (rc != MIPT_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(screen_buffer, scr.p, n * 4, hipMemcpyDeviceToHost));
+  return MIPT_OK;
+}
+
+extern "C" uint32_t mipt_path_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
+  return mipt::path_key(seed, pixel, sample);
+}

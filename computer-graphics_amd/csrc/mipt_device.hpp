@@ -1,0 +1,299 @@
+// mipt_device.hpp -- device-side data layout and arithmetic of the path-tracing hot path.
+//
+// Arithmetic contract: this translation unit is compiled with -ffp-contract=off, IEEE
+// division / square root and subnormals kept, so every float product and sum below is
+// rounded on its own, in the order written. The order is the reference's: GLM 0.9.7.2
+// (CW/glm/glm/detail/func_geometric.inl, func_matrix.inl, type_mat3x3.inl) as used by
+// CW/raytracer/Source/intersections.cpp, pathtracer.cpp, light.cpp, utils.cpp, sphere.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mipt.h"
+
+namespace mipt {
+
+// ---------------------------------------------------------------------------------------
+// HBM layout of a scene (built once per scene by mipt_scene_create)
+//
+// TriRec: what the intersection loop needs, one 64-byte record per triangle. Every lane of a
+// wave reads the SAME record in the same iteration, so the records are read through the
+// constant address space: scalar loads into SGPRs, shared by the 64 lanes, no VGPR cost.
+//   e1 = v1 - v0, e2 = v2 - v0               (intersections.cpp:17-18)
+//   c0 = e1.y*e2.z - e2.y*e1.z               ray-independent cofactors of A = (-dir, e1, e2):
+//   c1 = e1.x*e2.z - e2.x*e1.z               first-column cofactors of glm::determinant
+//   c2 = e1.x*e2.y - e2.x*e1.y               (func_matrix.inl:235-238) and first row of
+//                                            glm::inverse (type_mat3x3.inl:45-47)
+struct __attribute__((aligned(64))) TriRec {
+  float v0x, v0y, v0z, v0w;
+  float e1x, e1y, e1z, c0;
+  float e2x, e2y, e2z, c1;
+  float c2, pad0, pad1, pad2;
+};
+
+// ShadeRec: what shading needs about the ONE primitive a ray hit; gathered per lane.
+struct __attribute__((aligned(32))) ShadeRec {
+  float nx, ny, nz, nw;
+  float r, g, b;
+  uint32_t material;
+};
+
+struct __attribute__((aligned(16))) SphereRec {
+  float cx, cy, cz, cw;
+  float radius, r, g, b;
+  uint32_t material, pad0, pad1, pad2;
+};
+
+struct DeviceScene {
+  const TriRec* tris;
+  const ShadeRec* shade;  // n_tris triangle records followed by n_spheres sphere records
+  const SphereRec* spheres;
+  int n_tris;
+  int n_spheres;
+};
+
+enum StatSlot {
+  ST_PATHS = 0, ST_CLOSEST, ST_SHADOW, ST_TESTS, ST_GATE, ST_SPHERE, ST_FOG, ST_DIFFUSE, ST_MIRROR,
+  ST_GLASS, ST_COUNT
+};
+
+#define MIPT_CONST __attribute__((address_space(4)))
+
+template <typename T>
+__device__ __forceinline__ const T MIPT_CONST* as_constant(const T* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (const T MIPT_CONST*)p;
+#pragma clang diagnostic pop
+}
+
+// ---------------------------------------------------------------------------------------
+// small vector helpers, GLM operation order
+
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+
+__device__ __forceinline__ float dot3(V3 a, V3 b) {  // func_geometric.inl:69-70
+  float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
+  return (tx + ty) + tz;
+}
+__device__ __forceinline__ float dot4(V4 a, V4 b) {  // func_geometric.inl:79-80
+  float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z, tw = a.w * b.w;
+  return (tx + ty) + (tz + tw);
+}
+__device__ __forceinline__ V4 scale4(V4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+__device__ __forceinline__ V4 add4(V4 a, V4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+__device__ __forceinline__ V4 sub4(V4 a, V4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+__device__ __forceinline__ V4 normalize4(V4 v) {  // func_geometric.inl:158, func_exponential.inl:66
+  float s = 1.0f / sqrtf(dot4(v, v));
+  return scale4(v, s);
+}
+__device__ __forceinline__ V3 cross3(V3 x, V3 y) {  // func_geometric.inl:138-141
+  return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y};
+}
+
+// ---------------------------------------------------------------------------------------
+// RNG
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+
+__host__ __device__ inline uint32_t path_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
+  uint32_t k = seed ^ 0x9E3779B9u;
+  k ^= k >> 16; k *= 0x85EBCA6Bu; k ^= k >> 13; k *= 0xC2B2AE35u; k ^= k >> 16;
+  k += pixel;
+  k ^= k >> 16; k *= 0x85EBCA6Bu; k ^= k >> 13; k *= 0xC2B2AE35u; k ^= k >> 16;
+  k ^= (sample * 0x9E3779B1u + 0x7F4A7C15u);
+  k ^= k >> 16; k *= 0x85EBCA6Bu; k ^= k >> 13; k *= 0xC2B2AE35u; k ^= k >> 16;
+  return k;
+}
+
+// RNG_MODE MIPT_RNG_MINSTD_PATH: a = engine state.  MIPT_RNG_COUNTER: a = key, b = draw counter.
+struct Rng { uint32_t a, b; };
+
+template <int RNG_MODE>
+__device__ __forceinline__ void rng_begin(Rng& r, uint32_t seed, uint32_t pixel, uint32_t sample) {
+  uint32_t key = path_key(seed, pixel, sample);
+  if (RNG_MODE == MIPT_RNG_COUNTER) {
+    r.a = key; r.b = 0;
+  } else {
+    // 1 + key mod (2^31 - 2): key < 2^32 = 2*(2^31 - 2) + 4, so two conditional subtractions
+    uint32_t m = key;
+    if (m >= 2147483646u) m -= 2147483646u;
+    if (m >= 2147483646u) m -= 2147483646u;
+    r.a = 1u + m; r.b = 0;
+  }
+}
+
+template <int RNG_MODE>
+__device__ __forceinline__ float rng_next(Rng& r) {
+  if (RNG_MODE == MIPT_RNG_COUNTER) {
+    r.b += 1u;
+    uint32_t h = mix32(r.a + r.b * 0x9E3779B9u);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+  } else {
+    // minstd_rand0: x <- 16807 x mod (2^31 - 1); 2^31 = 1 (mod 2^31 - 1) folds the 46-bit product
+    uint64_t p = (uint64_t)r.a * 16807u;
+    uint32_t x = (uint32_t)(p & 0x7FFFFFFFu) + (uint32_t)(p >> 31);
+    if (x >= 0x7FFFFFFFu) x -= 0x7FFFFFFFu;
+    r.a = x;
+    // generate_canonical<float,24>: float(x - 1) / float(2147483646.0L) = float(x-1) * 2^-31,
+    // clamped below 1 (libstdc++ random.tcc:3366-3378)
+    float u = (float)(x - 1u) * 4.656612873077392578125e-10f;
+    return (u >= 1.0f) ? 0.99999994f : u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// libm functions whose host results the reference depends on
+
+// sinf/cosf of glibc >= 2.28 (the ARM optimized-routines algorithm: double-precision
+// quadrant reduction and two short polynomials) for 0 <= y < 120. The double arithmetic is
+// far finer than the final rounding to float, so this reproduces glibc's float results bit
+// for bit on the range the path uses (phi = 2*3.14*u, utils.cpp:12): verified exhaustively
+// for every float in [0, 6.28] on the build host.
+__device__ __forceinline__ void sincosf_glibc(float y, float& s_out, float& c_out) {
+  const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5,
+               C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+  const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+  double x = (double)y;
+  double sgn = 1.0, csgn = 1.0;
+  int n = 0;
+  uint32_t top = (__float_as_uint(y) >> 20) & 0x7FFu;
+  if (top < 0x398u) {  // |y| < 2^-12: sinf returns y, cosf returns 1
+    s_out = y; c_out = 1.0f;
+    return;
+  }
+  if (top >= 0x3F4u) {  // |y| >= pi/4 (compared on the top 12 bits, as glibc does)
+    double r = x * 0x1.45F306DC9C883p+23;
+    n = ((int32_t)r + 0x800000) >> 24;
+    x = x - (double)n * 0x1.921FB54442D18p0;
+    sgn = (n & 1) != ((n >> 1) & 1) ? -1.0 : 1.0;  // sign table {1,-1,-1,1}[n & 3]
+    csgn = (n & 2) ? -1.0 : 1.0;                   // second coefficient table negates the cosine
+  }
+  double xs = x * sgn;
+  double x2 = x * x;
+  // sine polynomial
+  double x3 = xs * x2;
+  double s1 = S2 + x2 * S3;
+  double x7 = x3 * x2;
+  double sp = xs + x3 * S1;
+  float sin_poly = (float)(sp + x7 * s1);
+  // cosine polynomial
+  double x4 = x2 * x2;
+  double c2 = csgn * C3 + x2 * (csgn * C4);
+  double c1 = csgn * C0 + x2 * (csgn * C1);
+  double x6 = x4 * x2;
+  double cp = c1 + x4 * (csgn * C2);
+  float cos_poly = (float)(cp + x6 * c2);
+  // sinf uses polynomial (n & 1), cosf polynomial ((n ^ 1) & 1)
+  s_out = (n & 1) ? cos_poly : sin_poly;
+  c_out = (n & 1) ? sin_poly : cos_poly;
+}
+
+// powf(x, 5.0f) (pathtracer.cpp:47). x^5 in double rounded once to float is the correctly
+// rounded result; glibc's powf differs from it for < 0.07 % of x in [0,1], by one ulp, and
+// the value only feeds the comparison `u > Rprob`.
+__device__ __forceinline__ float pow5f(float x) {
+  double d = (double)x;
+  double d2 = d * d;
+  return (float)((d2 * d2) * d);
+}
+
+// ---------------------------------------------------------------------------------------
+// ray / triangle test, intersections.cpp:11-37 and :61-82
+
+struct HitAcc {
+  float lim;  // closest: minimumDistance; shadow: inter.distance, -1 once occluded
+  int idx;    // closest: winning primitive, -1 = none; shadow: 1 = occluded
+  float by, bz;  // barycentrics x.y, x.z of the winning triangle
+};
+
+template <bool STATS>
+__device__ __forceinline__ void tri_test(const TriRec MIPT_CONST* __restrict__ T, int i, float ox,
+                                         float oy, float oz, float px, float py, float pz,
+                                         bool shadow, HitAcc& h, uint32_t& n_tests, uint32_t& n_gate) {
+  // existsIntersection leaves its loop at the first accepted triangle (:79); the lane keeps
+  // scanning here (its gate can no longer pass), so those iterations are not counted as tests
+  if (STATS) n_tests += (shadow && h.idx) ? 0u : 1u;
+  // b = origin - v0 (:19); A = (-dir, e1, e2), m = A with column 0 replaced by b (:20-22)
+  const float bx = ox - T->v0x, by = oy - T->v0y, bz = oz - T->v0z;
+  const float e1x = T->e1x, e1y = T->e1y, e1z = T->e1z;
+  const float e2x = T->e2x, e2y = T->e2y, e2z = T->e2z;
+  const float c0 = T->c0;
+  const float m1 = by * e2z - e2y * bz;
+  const float m2 = by * e1z - e1y * bz;
+  const float detM = ((bx * c0) - (e1x * m1)) + (e2x * m2);
+  const float k1 = py * e2z - e2y * pz;
+  const float k2 = py * e1z - e1y * pz;
+  const float detA = ((px * c0) - (e1x * k1)) + (e2x * k2);
+  const float t = detM / detA;  // :23
+  if (t >= 0.0f && t <= h.lim) {  // :25 / :75
+    if (STATS) n_gate++;
+    // glm::inverse(A) * b (:26): type_mat3x3.inl:39-53 then :510-512
+    const float ood = 1.0f / detA;
+    const float i00 = c0 * ood;
+    const float i10 = -(T->c1) * ood;
+    const float i20 = T->c2 * ood;
+    const float i01 = -k1 * ood;
+    const float i11 = (px * e2z - e2x * pz) * ood;
+    const float i21 = -(px * e2y - e2x * py) * ood;
+    const float i02 = k2 * ood;
+    const float i12 = -(px * e1z - e1x * pz) * ood;
+    const float i22 = (px * e1y - e1x * py) * ood;
+    const float x0 = (i00 * bx + i10 * by) + i20 * bz;
+    const float x1 = (i01 * bx + i11 * by) + i21 * bz;
+    const float x2 = (i02 * bx + i12 * by) + i22 * bz;
+    // :27 compares the float sum with the double 1.001, i.e. with the largest float below it;
+    // :77 (shadow rays) compares with 1
+    const float bound = shadow ? 1.0f : __uint_as_float(0x3F8020C4u);
+    if (x1 >= 0.0f && x2 >= 0.0f && (x1 + x2) <= bound) {
+      if (shadow) {
+        h.lim = -1.0f;  // `break` (:79): no later triangle can pass t >= 0 && t <= -1
+        h.idx = 1;
+      } else {
+        h.lim = fabsf(x0);  // :28
+        h.idx = i;
+        h.by = x1;
+        h.bz = x2;
+      }
+    }
+  }
+}
+
+// Sphere::intersect + solveQuadratic (sphere.h:23-45, utils.cpp:34-49) and the acceptance test
+// of intersections.cpp:42. Returns true when the sphere becomes the closest hit.
+__device__ __forceinline__ bool sphere_test(const SphereRec& S, V4 o, V4 d, float& lim, V4& pos, V4& nrm) {
+  V4 c = {S.cx, S.cy, S.cz, S.cw};
+  V4 L = sub4(o, c);
+  float a = dot4(d, d);
+  float b = 2.0f * dot4(d, L);
+  float cc = dot4(L, L) - S.radius * S.radius;
+  float discr = b * b - (4.0f * a) * cc;
+  float x0, x1;
+  if (discr < 0.0f) return false;
+  if (discr == 0.0f) {
+    x0 = x1 = (float)((-0.5 * (double)b) / (double)a);
+  } else {
+    float sq = sqrtf(discr);
+    float q = (b > 0.0f) ? (float)(-0.5 * (double)(b + sq)) : (float)(-0.5 * (double)(b - sq));
+    x0 = q / a;
+    x1 = cc / q;
+  }
+  if (x0 > x1) { float tmp = x0; x0 = x1; x1 = tmp; }
+  float t0 = x0;
+  if (t0 < 0.0f) {
+    t0 = x1;
+    if (t0 < 0.0f) return false;
+  }
+  if (!((double)t0 >= 1e-6 && t0 <= lim)) return false;
+  lim = t0;
+  pos = add4(o, scale4(d, t0));
+  nrm = normalize4(sub4(pos, c));
+  return true;
+}
+
+}  // namespace mipt

@@ -141,6 +141,18 @@ typedef struct MiptStats {
 typedef struct MiptScene MiptScene; /* opaque */
 
 void mipt_params_default(MiptParams* p, int width, int height);
+
+/* The reference's built-in scenes: which = 0 LoadTestModel, 1 LoadTestModelColorBleeding,
+ * 2 LoadTestModelGlassCube, 3 LoadTestModelNone (TestModelH.h:55-201, 203-349, 351-482,
+ * 484-580), bit-for-bit the triangles those functions produce. Writes at most `capacity`
+ * triangles (30 suffice) and returns the count (30 / 30 / 22 / 10) or a MiptError. */
+int mipt_load_test_model(int which, MiptTriangle* out, size_t capacity);
+/* reset_camera (camera.cpp:4-13) with focalLength = width. */
+void mipt_default_camera(MiptCamera* cam, int width);
+/* reset_light (light.cpp:6-9); glass_scene != 0 gives the light main.cpp:68-69 sets for
+ * the glassCube / glassCubeSphere / glassWolf scenes. */
+void mipt_default_light(MiptLight* light, int glass_scene);
+
 const char* mipt_last_error(void);
 /* "mipt <version> gfx950 hip" */
 const char* mipt_version(void);

@@ -1,0 +1,95 @@
+"""CPU-side checks of libmipt.so: it loads, exports every symbol include/mipt.h declares,
+and its host-side logic (scene builders, defaults, key function) is right. No kernel runs."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    if not os.path.exists(pkg.abi.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return pkg.abi.load_library()
+
+
+def test_header_symbols_all_exported(pkg, lib):
+    header = open(os.path.join(ROOT, "include", "mipt.h")).read()
+    declared = set(re.findall(r"\b(mipt_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(pkg.abi.EXPORTS), declared ^ set(pkg.abi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mipt_version().decode().startswith("mipt ")
+
+
+def test_struct_layouts(pkg):
+    abi = pkg.abi
+    assert C.sizeof(abi.MiptTriangle) == 80 and C.sizeof(abi.MiptSphere) == 36
+    assert C.sizeof(abi.MiptCamera) == 4 * (1 + 4 + 16 + 16)
+    assert C.sizeof(abi.MiptLight) == 28
+    assert C.sizeof(abi.MiptParams) == 52
+    assert C.sizeof(abi.MiptStats) == 88
+
+
+@pytest.mark.parametrize("which,name", [(0, "cornell"), (1, "colorbleeding"), (2, "glasscube"), (3, "none")])
+def test_library_scene_builders_match_reference_dump(pkg, lib, O, which, name):
+    ours = pkg.api.load_test_model(which)
+    ref = O.golden_scene(name)
+    assert len(ours) == len(ref)
+    for field in ("v0", "v1", "v2", "color", "normal"):
+        assert np.array_equal(bits(ours[field]), bits(ref[field])), field
+    assert np.array_equal(ours["material"], ref["material"])
+
+
+def test_scene_builder_rejects_bad_arguments(pkg, lib):
+    buf = np.zeros(30, dtype=pkg.abi.TRIANGLE_DTYPE)
+    assert lib.mipt_load_test_model(9, buf.ctypes.data, 30) == pkg.abi.MIPT_E_INVALID
+    assert lib.mipt_load_test_model(0, buf.ctypes.data, 29) == pkg.abi.MIPT_E_INVALID
+    assert lib.mipt_load_test_model(0, None, 30) == pkg.abi.MIPT_E_INVALID
+
+
+def test_defaults_match_oracle(pkg, lib, O):
+    abi, api = pkg.abi, pkg.api
+    for w in (500, 1024):
+        a, b = api.default_camera(w), O.default_camera(w)
+        assert bytes(a) == bytes(b)
+    for glass in (False, True):
+        assert bytes(api.default_light(glass)) == bytes(O.default_light(glass))
+    assert bytes(api.default_params(640, 480)) == bytes(O.default_params(640, 480))
+    p = api.default_params(8, 8)
+    assert (p.max_depth, p.rng_mode) == (10, abi.RNG_MINSTD_PATH)
+    assert np.float32(p.rr_prob) == np.float32(0.15) and np.float32(p.glass_weight) == np.float32(1.15)
+
+
+def test_path_key_matches_oracle(pkg, lib, O):
+    o = O.oracle()
+    rng = np.random.default_rng(0)
+    for seed, pixel, sample in rng.integers(0, 2**32, (2000, 3), dtype=np.uint64):
+        assert lib.mipt_path_key(int(seed), int(pixel), int(sample)) == o.or_path_key(int(seed), int(pixel), int(sample))
+    keys = {lib.mipt_path_key(0, p, s) for p in range(64) for s in range(64)}
+    assert len(keys) == 64 * 64
+
+
+def test_argument_checks_need_no_gpu(pkg, lib):
+    abi = pkg.abi
+    h = C.c_void_p()
+    assert lib.mipt_scene_create(None, 3, None, 0, 0, C.byref(h)) == abi.MIPT_E_INVALID
+    assert b"null primitive array" in lib.mipt_last_error()
+    assert lib.mipt_scene_create(None, 0, None, 0, 0, None) == abi.MIPT_E_INVALID
+    assert lib.mipt_closest_hit(None, None, None, 0, None, None, None) == abi.MIPT_E_INVALID
+    st = abi.MiptStats()
+    assert lib.mipt_get_stats(None, C.byref(st)) == abi.MIPT_E_INVALID
+
+
+def test_missing_library_fails_loudly(pkg, tmp_path):
+    with pytest.raises(pkg.abi.MiptLibraryMissing):
+        pkg.abi.load_library(str(tmp_path / "libmipt.so"))
