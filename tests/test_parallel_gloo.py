@@ -1,0 +1,82 @@
+"""The sample-split + sum-reduce decomposition with 2 and 3 ranks over gloo, on CPU.
+
+The renderer plugged into parallel.render_distributed here is the CPU oracle (the GPU one has
+the same "add samples [b, b+n) into the image" contract); the check is that N ranks together
+produce the image one rank produces for the whole range.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_path):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import __graft_entry__ as g
+    import oracle_lib as O
+    pkg = g.load_package()
+    from computer_graphics_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H = 24, 20
+    tris = O.load_test_model(2)
+    cam, light = O.default_camera(W), O.default_light(True)
+    params = O.default_params(W, H, rng_mode=pkg.abi.RNG_COUNTER, seed=4)
+
+    def render_fn(begin, count, image):
+        acc = image.numpy().reshape(W, H, 3)
+        O.render_accumulate(tris, None, cam, light, params, begin, count, accum=acc)
+
+    rank_image = torch.zeros(W * H * 3, dtype=torch.float32)
+    total = torch.zeros(W * H * 3, dtype=torch.float32) if rank == 0 else None
+    # two consecutive calls with ranges that do not divide evenly
+    parallel.render_distributed(render_fn, 0, 11, rank, world, rank_image, total)
+    parallel.render_distributed(render_fn, 11, 6, rank, world, rank_image, total)
+    if rank == 0:
+        np.save(out_path, total.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sample_split_equals_single_rank(tmp_path, world, O, pkg):
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out).reshape(24, 20, 3)
+    tris = O.load_test_model(2)
+    cam, light = O.default_camera(24), O.default_light(True)
+    params = O.default_params(24, 20, rng_mode=pkg.abi.RNG_COUNTER, seed=4)
+    want, _ = O.render_accumulate(tris, None, cam, light, params, 0, 17)
+    assert want.sum() > 0
+    # the same 17 samples per pixel, added in a different order
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-7)
+
+
+def test_rank_sample_range_partitions(pkg):
+    from computer_graphics_amd import parallel
+    for count in (0, 1, 7, 1024, 4096):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.rank_sample_range(5, count, r, world) for r in range(world)]
+            assert sum(c for _, c in spans) == count
+            pos = 5
+            for b, c in spans:
+                assert b == pos
+                pos += c
+    with pytest.raises(ValueError):
+        parallel.rank_sample_range(0, 4, 2, 2)
