@@ -203,6 +203,11 @@ __device__ __forceinline__ float pow5f(float x) {
   return (float)((d2 * d2) * d);
 }
 
+// Transcendentals of the fog (which has no reference code): evaluated in double and rounded
+// once to float, so that host and device libms agree on the float result.
+__device__ __forceinline__ float fog_logf(float x) { return (float)log((double)x); }
+__device__ __forceinline__ float fog_expf(float x) { return (float)exp((double)x); }
+
 // ---------------------------------------------------------------------------------------
 // ray / triangle test, intersections.cpp:11-37 and :61-82
 

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(BLOCK) void k_paths(const PathArgs a) {
           const float len = sqrtf(dot3({d.x, d.y, d.z}, {d.x, d.y, d.z}));
           const float dist = h.lim * len;
           const float uf = rng_next<RNG_MODE>(rng);
-          const float fs = -logf(1.0f - uf) / P.fog_sigma_t;
+          const float fs = -fog_logf(1.0f - uf) / P.fog_sigma_t;
           if (fs < dist) {
             const float k = fs / len;
             o.x = o.x + d.x * k; o.y = o.y + d.y * k; o.z = o.z + d.z * k; o.w = 1.0f;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(BLOCK) void k_paths(const PathArgs a) {
             Lg = (a.light_col[1] * m) / den;
             Lb = (a.light_col[2] * m) / den;
             if (fog) {
-              const float tr = expf(-(P.fog_sigma_t * r));
+              const float tr = fog_expf(-(P.fog_sigma_t * r));
               Lr = Lr * tr; Lg = Lg * tr; Lb = Lb * tr;
             }
             if (sh.material != MIPT_MAT_GLASS) {  // pathtracer.cpp:88-93
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(BLOCK) void k_paths(const PathArgs a) {
             }
             o = add4(pos, scale4(vecr, 0.001f));  // light.cpp:25
           } else {
-            const float tr = expf(-(P.fog_sigma_t * r));
+            const float tr = fog_expf(-(P.fog_sigma_t * r));
             const float phase = 1.0f / (4.0f * 3.14159f);
             Lr = (((a.light_col[0] * phase) / den) * tr) * P.fog_albedo;
             Lg = (((a.light_col[1] * phase) / den) * tr) * P.fog_albedo;
@@ -298,7 +298,9 @@ __global__ __launch_bounds__(BLOCK) void k_paths(const PathArgs a) {
           const float s2 = 1.0f - z * z;
           const float rxy = sqrtf(s2 < 0.f ? 0.f : s2);
           const float phi = 6.28318530718f * u2;
-          d = {rxy * cosf(phi), rxy * sinf(phi), z, 0.0f};
+          float sn, cs;
+          sincosf_glibc(phi, sn, cs);
+          d = {rxy * cs, rxy * sn, z, 0.0f};
           tags[sp * BLOCK + tid] = TAG_FOG;
           sp++; depth++;
         } else {

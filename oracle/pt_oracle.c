@@ -426,6 +426,12 @@ typedef struct {
   OrCounters* cn;
 } OrCtx;
 
+/* The fog's transcendental functions: evaluated in double and rounded once to float, so that
+ * a host libm and a device libm give the same float (both are far more accurate than the final
+ * rounding). The fog has no reference code; this choice is part of its definition here. */
+static float fog_logf(float x) { return (float)log((double)x); }
+static float fog_expf(float x) { return (float)exp((double)x); }
+
 /* directLight (light.cpp:13-31). fog: transmittance along the light segment. */
 static void direct_light(const OrCtx* cx, const float pos[4], const float normal[4],
                          const float lpos[4], const float lcol[3], float out[3]) {
@@ -443,7 +449,7 @@ static void direct_light(const OrCtx* cx, const float pos[4], const float normal
   or_normalize4(vecr, sd); /* Ray ctor normalises again (ray.h:11-12) */
   if (exists_intersection(cx->sc, so, sd, r, cx->cn)) { out[0] = out[1] = out[2] = 0.f; return; }
   if (cx->p->fog_sigma_t > 0.f) {
-    float tr = expf(-(cx->p->fog_sigma_t * r));
+    float tr = fog_expf(-(cx->p->fog_sigma_t * r));
     for (int k = 0; k < 3; k++) out[k] = out[k] * tr;
   }
 }
@@ -474,7 +480,7 @@ static void fog_vertex(const OrCtx* cx, float o[4], float d[4], int depth, float
     float sd[4];
     or_normalize4(vecr, sd);
     if (exists_intersection(cx->sc, o, sd, r, cx->cn)) return;
-    float tr = expf(-(p->fog_sigma_t * r));
+    float tr = fog_expf(-(p->fog_sigma_t * r));
     float phase = 1.0f / (4.0f * 3.14159f);
     for (int k = 0; k < 3; k++) color[k] = (((cx->light->color[k] * phase) / den) * tr) * p->fog_albedo;
     return;
@@ -586,7 +592,7 @@ static void trace(const OrCtx* cx, float o[4], float d[4], int depth, float colo
     float len = sqrtf(or_dot3(d, d));
     float dist = hit.distance * len;
     float uf = rng_next(cx->rng);
-    float s = -logf(1.0f - uf) / p->fog_sigma_t;
+    float s = -fog_logf(1.0f - uf) / p->fog_sigma_t;
     if (s < dist) {
       float k = s / len;
       for (int q = 0; q < 3; q++) o[q] = o[q] + d[q] * k;
