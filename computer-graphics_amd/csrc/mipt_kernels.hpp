@@ -126,8 +126,14 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
 // applied when the path ends, deepest vertex first, from a small per-lane stack of primitive
 // tags kept in LDS.
 
+#ifdef MIPT_WAVES_PER_EU
+#define MIPT_PATHS_OCC __attribute__((amdgpu_waves_per_eu(MIPT_WAVES_PER_EU, MIPT_WAVES_PER_EU)))
+#else
+#define MIPT_PATHS_OCC
+#endif
+
 template <int RNG_MODE, bool STATS, bool LIST>
-__global__ __launch_bounds__(BLOCK) void k_paths(const PathArgs a) {
+__global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a) {
   extern __shared__ uint32_t lds_stack[];  // [max_depth][BLOCK] tags, then sphere normals
   const int tid = threadIdx.x;
   const MiptParams& P = a.p;

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3's rocpd SQLite output (ROCm 7.2 default) into the plain-text summaries kept
+under profiles/: per-kernel call count / total / average duration (the `--stats` view) and,
+for --pmc runs, per-kernel sums of every collected counter.
+
+    python tools/rocpd_summary.py <results.db> [more.db ...] > profiles/<name>.txt
+"""
+import sqlite3
+import sys
+
+
+def main():
+    for path in sys.argv[1:]:
+        db = sqlite3.connect(path)
+        c = db.cursor()
+        print(f"# {path}")
+        rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+        if rows:
+            print("## kernel-trace --stats (durations in microseconds)")
+            print(f"{'calls':>6} {'total_us':>14} {'avg_us':>14} {'pct':>7}  name")
+            for name, calls, total, avg, pct in rows:
+                print(f"{calls:6d} {total:14.3f} {avg:14.3f} {pct:7.3f}  {name}")
+        try:
+            pmc = list(c.execute(
+                "select kernel_name, counter_name, count(distinct dispatch_id), sum(value), "
+                "max(vgpr_count), max(sgpr_count), max(lds_block_size), max(grid_size), max(workgroup_size) "
+                "from counters_collection group by kernel_name, counter_name order by kernel_name, counter_name"))
+        except sqlite3.OperationalError:
+            pmc = []
+        if pmc:
+            print("## pmc (sum over dispatches)")
+            last = None
+            for k, cn, nd, v, vg, sg, lds, grid, wg in pmc:
+                if k != last:
+                    print(f"kernel {k}\n  dispatches={nd} vgpr={vg} sgpr={sg} lds={lds} grid={grid} wg={wg}")
+                    last = k
+                print(f"    {cn:28s} {v:.6g}")
+        print()
+
+
+if __name__ == "__main__":
+    main()
