@@ -1,0 +1,176 @@
+// mipt_adapter.hpp -- C++ host adapter between the reference raytracer's own types and the
+// C ABI of libmipt.so.
+//
+// The reference (CW/raytracer/Source) is one translation unit built on glm::vec3/vec4/mat4.
+// This header is duck-typed on member names (.x .y .z .w, operator[] for matrices), so it
+// takes the reference's `Triangle` (TestModelH.h:11-49), `Sphere` (sphere.h:9-16), `Camera`,
+// `Light`, `Intersection` (definitions.h:16-37) and `Ray` (ray.h:6-13) as they are, and any
+// other struct with the same member names. It offers the reference's call shapes:
+//
+//   mipt_host::GpuScene gpu(triangles, spheres);                        after scene load, main.cpp:63-94
+//   mipt_host::closestIntersection(gpu, ray, triangles, spheres, inter) intersections.h:7
+//   mipt_host::existsIntersection(gpu, ray, triangles, inter)           intersections.h:12
+//   mipt_host::Draw(gpu, screen, cam, light, pixels, samplesSeenSoFar)  definitions.h:61
+//
+// Errors: the reference has no error channel (its functions return bool / void), so the
+// adapter throws std::runtime_error carrying mipt_last_error().
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mipt.h"
+
+namespace mipt_host {
+
+inline void check(int rc) {
+  if (rc != MIPT_OK) throw std::runtime_error(std::string("mipt: ") + mipt_last_error());
+}
+
+// material.h:5-11 stores `const char* type`; pathtracer.cpp:88,103-110 compares it with strcmp
+inline uint32_t material_code(const char* type) {
+  if (!type) return MIPT_MAT_NONE;
+  if (!std::strcmp(type, "diffuse")) return MIPT_MAT_DIFFUSE;
+  if (!std::strcmp(type, "mirror")) return MIPT_MAT_MIRROR;
+  if (!std::strcmp(type, "glass")) return MIPT_MAT_GLASS;
+  if (!std::strcmp(type, "specular")) return MIPT_MAT_SPECULAR;
+  return MIPT_MAT_NONE;
+}
+
+inline const char* material_name(uint32_t code) {
+  static const char* names[] = {"diffuse", "mirror", "glass", "specular", "none"};
+  return names[code <= (uint32_t)MIPT_MAT_NONE ? code : (uint32_t)MIPT_MAT_NONE];
+}
+
+template <class V4> inline void put4(float out[4], const V4& v) { out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
+template <class V3> inline void put3(float out[3], const V3& v) { out[0] = v.x; out[1] = v.y; out[2] = v.z; }
+
+template <class TriangleT> inline MiptTriangle to_mipt(const TriangleT& t) {
+  MiptTriangle m;
+  put4(m.v0, t.v0); put4(m.v1, t.v1); put4(m.v2, t.v2);
+  put3(m.color, t.color); put4(m.normal, t.normal);
+  m.material = material_code(t.material.type);
+  return m;
+}
+
+template <class SphereT> inline MiptSphere to_mipt_sphere(const SphereT& s) {
+  MiptSphere m;
+  m.radius = s.radius;
+  put4(m.center, s.center); put3(m.color, s.color);
+  m.material = material_code(s.material.type);
+  return m;
+}
+
+template <class CameraT> inline MiptCamera to_mipt_camera(const CameraT& c) {
+  MiptCamera m;
+  m.focal = c.focalLength;
+  put4(m.pos, c.cameraPos);
+  for (int col = 0; col < 4; ++col)
+    for (int row = 0; row < 4; ++row) {
+      m.rot_x[4 * col + row] = c.cameraRotationX[col][row];
+      m.rot_y[4 * col + row] = c.cameraRotationY[col][row];
+    }
+  return m;
+}
+
+template <class LightT> inline MiptLight to_mipt_light(const LightT& l) {
+  MiptLight m;
+  put4(m.pos, l.lightPos); put3(m.color, l.lightColor);
+  return m;
+}
+
+// Owns the device copy of an (immutable after load) scene.
+class GpuScene {
+ public:
+  template <class TriangleT, class SphereT>
+  GpuScene(const std::vector<TriangleT>& triangles, const std::vector<SphereT>& spheres, int device = 0) {
+    std::vector<MiptTriangle> t;
+    t.reserve(triangles.size());
+    for (const auto& x : triangles) t.push_back(to_mipt(x));
+    std::vector<MiptSphere> s;
+    s.reserve(spheres.size());
+    for (const auto& x : spheres) s.push_back(to_mipt_sphere(x));
+    n_tris_ = t.size();
+    check(mipt_scene_create(t.data(), t.size(), s.data(), s.size(), device, &h_));
+  }
+  ~GpuScene() { mipt_scene_destroy(h_); }
+  GpuScene(const GpuScene&) = delete;
+  GpuScene& operator=(const GpuScene&) = delete;
+  MiptScene* handle() const { return h_; }
+  size_t n_tris() const { return n_tris_; }
+  MiptParams params;  // filled by Draw() from the screen size on first use; edit to taste
+  bool params_set = false;
+
+ private:
+  MiptScene* h_ = nullptr;
+  size_t n_tris_ = 0;
+};
+
+// closestIntersection (intersections.cpp:6-55) for one ray. `triangles` / `spheres` are the
+// host vectors the scene was built from; colour, normal and material of the hit primitive are
+// copied from them exactly as the reference does (:31-33, :47-49).
+template <class RayT, class TriangleT, class SphereT, class IntersectionT>
+inline bool closestIntersection(GpuScene& gpu, const RayT& ray, const std::vector<TriangleT>& triangles,
+                                const std::vector<SphereT>& spheres, IntersectionT& out) {
+  float o[4], d[4], pos[4] = {0, 0, 0, 0}, t = 0.f;
+  int32_t idx = -1;
+  put4(o, ray.origin); put4(d, ray.direction);
+  check(mipt_closest_hit(gpu.handle(), o, d, 1, &idx, &t, pos));
+  if (idx < 0) return false;
+  out.position.x = pos[0]; out.position.y = pos[1]; out.position.z = pos[2]; out.position.w = pos[3];
+  out.distance = t;
+  if ((size_t)idx < triangles.size()) {
+    out.color = triangles[idx].color;
+    out.normal = triangles[idx].normal;
+    out.material = triangles[idx].material;
+  } else {
+    const SphereT& s = spheres[idx - triangles.size()];
+    out.color = s.color;
+    out.material = s.material;
+    out.normal = s.normal(out.position);
+  }
+  return true;
+}
+
+// existsIntersection (intersections.cpp:57-85): inter.distance is the maximum t.
+template <class RayT, class TriangleT, class IntersectionT>
+inline bool existsIntersection(GpuScene& gpu, const RayT& ray, const std::vector<TriangleT>&, const IntersectionT& inter) {
+  float o[4], d[4], max_t = inter.distance;
+  uint8_t occ = 0;
+  put4(o, ray.origin); put4(d, ray.direction);
+  check(mipt_any_hit(gpu.handle(), o, d, &max_t, 1, &occ));
+  return occ != 0;
+}
+
+// Draw (main.cpp:110-146): `samples_per_call` samples of every pixel are added to `pixels`
+// (W separately allocated columns of H vec3, main.cpp:55-57), samplesSeenSoFar advances by the
+// same amount, and screen->buffer receives the tonemapped ARGB image.
+template <class ScreenT, class CameraT, class LightT, class Vec3T>
+inline void Draw(GpuScene& gpu, ScreenT* screen, const CameraT& cam, const LightT& light, Vec3T** pixels,
+                 int& samplesSeenSoFar, int samples_per_call = 1) {
+  const int W = screen->width, H = screen->height;
+  if (!gpu.params_set) { mipt_params_default(&gpu.params, W, H); gpu.params_set = true; }
+  gpu.params.width = W; gpu.params.height = H;
+  std::vector<float> accum((size_t)W * H * 3);
+  for (int x = 0; x < W; ++x)
+    for (int y = 0; y < H; ++y) {
+      float* a = &accum[((size_t)x * H + y) * 3];
+      a[0] = pixels[x][y].x; a[1] = pixels[x][y].y; a[2] = pixels[x][y].z;
+    }
+  const MiptCamera c = to_mipt_camera(cam);
+  const MiptLight l = to_mipt_light(light);
+  check(mipt_render_accumulate(gpu.handle(), &c, &l, &gpu.params, (uint32_t)samplesSeenSoFar,
+                               (uint32_t)samples_per_call, accum.data()));
+  samplesSeenSoFar += samples_per_call;
+  for (int x = 0; x < W; ++x)
+    for (int y = 0; y < H; ++y) {
+      const float* a = &accum[((size_t)x * H + y) * 3];
+      pixels[x][y].x = a[0]; pixels[x][y].y = a[1]; pixels[x][y].z = a[2];
+    }
+  check(mipt_resolve_argb(gpu.handle(), accum.data(), W, H, (uint32_t)samplesSeenSoFar, screen->buffer));
+}
+
+}  // namespace mipt_host

@@ -1,0 +1,80 @@
+"""The C++ host adapter (computer-graphics_amd/host/mipt_adapter.hpp).
+
+CPU part: compiled against the reference's own Triangle / glm types (read in place from the
+reference tree, skipped where it is absent) and checked against the golden scene dumps.
+GPU part: the prebuilt host_demo drives closestIntersection / existsIntersection / Draw through
+the adapter; its results must equal the Python host's for the same inputs.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "CW/raytracer/Source")), reason="reference tree not present")
+def test_adapter_accepts_reference_types(tmp_path, pkg, O):
+    abi = pkg.abi
+    exe = str(tmp_path / "adapter_ref_types")
+    subprocess.run(["g++", "-O1", "-std=c++11", "-ffp-contract=off",
+                    f"-I{REF}/CW/glm", f"-I{REF}/CW/raytracer/Source",
+                    f"-I{ROOT}/computer-graphics_amd/host",
+                    os.path.join(ROOT, "tests/host_cpp/adapter_ref_types.cpp"),
+                    f"-L{ROOT}/computer-graphics_amd", "-lmipt", f"-Wl,-rpath,{ROOT}/computer-graphics_amd",
+                    "-o", exe], check=True, capture_output=True)
+    blob = subprocess.run([exe], check=True, capture_output=True).stdout
+    off = 0
+    for name in ("cornell", "colorbleeding", "glasscube", "none"):
+        ref = O.golden_scene(name)
+        got = np.frombuffer(blob, dtype=abi.TRIANGLE_DTYPE, count=len(ref), offset=off)
+        off += len(ref) * 80
+        assert got.tobytes() == ref.tobytes(), name
+    cam = abi.MiptCamera.from_buffer_copy(blob[off:off + C.sizeof(abi.MiptCamera)])
+    off += C.sizeof(abi.MiptCamera)
+    assert cam.focal == 500 and list(cam.pos) == [0, 0, -3, 1]
+    assert list(cam.rot_y) == [float(i) for i in range(1, 17)]           # column-major, as glm stores it
+    assert cam.rot_x[5] == 0.5 and cam.rot_x[6] == 0.25 and cam.rot_x[9] == -0.25
+    light = abi.MiptLight.from_buffer_copy(blob[off:off + 28])
+    off += 28
+    assert bytes(light) == bytes(O.default_light(True))
+    sph = np.frombuffer(blob, dtype=abi.SPHERE_DTYPE, count=1, offset=off)
+    assert sph["material"][0] == abi.MAT_GLASS and sph["radius"][0] == np.float32(0.3)
+    assert len(blob) == off + 36
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,size,frames,spf", [(2, 64, 2, 4), (0, 48, 3, 2)])
+def test_host_demo_matches_python_host(pkg, which, size, frames, spf):
+    exe = os.path.join(ROOT, "computer-graphics_amd", "host", "host_demo")
+    assert os.path.exists(exe), "host_demo is built by __graft_entry__.build()"
+    out = subprocess.run([exe, str(which), str(size), str(frames), str(spf)], check=True,
+                         capture_output=True, text=True).stdout.strip().splitlines()[-1]
+    kv = dict(item.split("=") for item in out.split())
+    api, abi = pkg.api, pkg.abi
+    tris = api.load_test_model(which)
+    cam, light = api.default_camera(size), api.default_light(which >= 2)
+    sc = api.Scene(tris)
+    o = np.array([[0, 0, -3, 1]], dtype=np.float32)
+    d = np.array([[0.25 * size, -0.125 * size, size, 0]], dtype=np.float32)
+    idx, t, _ = sc.closest_hit(o, d)
+    assert int(kv["hit"]) == int(idx[0] >= 0)
+    if idx[0] >= 0:
+        assert int(kv["tbits"], 16) == int(t.view(np.uint32)[0])
+        names = {v: k for k, v in abi.MATERIAL_NAMES.items()}
+        assert kv["material"] == names[int(tris["material"][idx[0]])]
+    occ = sc.any_hit(np.array([[0, 0.9, -0.5, 1]], dtype=np.float32), np.array([[0, -1, 0, 0]], dtype=np.float32),
+                     np.array([1.5], dtype=np.float32))
+    assert int(kv["occluded"]) == int(occ[0])
+    p = api.default_params(size, size)
+    acc = np.zeros((size, size, 3), dtype=np.float32)
+    for f in range(frames):
+        sc.render_accumulate(cam, light, p, f * spf, spf, accum=acc)
+    img = sc.resolve_argb(acc, frames * spf)
+    sc.close()
+    assert int(kv["samples"]) == frames * spf and int(kv["n_tris"]) == len(tris)
+    assert int(kv["screen_sum"]) == int(img.astype(np.uint64).sum())
+    assert abs(float(kv["pixel_sum"]) - float(acc.astype(np.float64).sum())) <= 1e-9 * abs(float(acc.sum()))
