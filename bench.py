@@ -169,8 +169,8 @@ def main():
                          "tri_tests": st.tri_tests, "gate_passes": st.gate_passes,
                          "note": "algorithmic flops = 26*tests + 79*gate_passes of the reference's triangle test; "
                                  "FMA contraction is forbidden by the bit-exact contract, so 78.6 TFLOP/s is the "
-                                 "issue-rate roof; HBM traffic of this kernel is negligible (22 triangles, one "
-                                 "12.6 MB image write per 64-sample chunk)"},
+                                 "issue-rate roof; HBM traffic of this kernel is negligible (22 triangles in the "
+                                 "scalar cache, 12 bytes written per 16-sample work item)"},
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(abi, tris, cam, light, params)

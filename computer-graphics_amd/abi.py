@@ -81,7 +81,7 @@ EXPORTS = [
     "mipt_scene_destroy", "mipt_closest_hit", "mipt_any_hit", "mipt_render_accumulate",
     "mipt_resolve_argb", "mipt_trace_paths", "mipt_closest_hit_dev", "mipt_any_hit_dev",
     "mipt_render_accumulate_dev", "mipt_resolve_argb_dev", "mipt_get_stats", "mipt_path_key",
-    "mipt_load_test_model", "mipt_default_camera", "mipt_default_light",
+    "mipt_load_test_model", "mipt_default_camera", "mipt_default_light", "mipt_debug_selfcheck",
 ]
 
 
@@ -129,6 +129,7 @@ def load_library(path=None):
     lib.mipt_get_stats.argtypes = [vp, P(MiptStats)]
     lib.mipt_path_key.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     lib.mipt_path_key.restype = C.c_uint32
+    lib.mipt_debug_selfcheck.argtypes = [vp, C.c_uint64, C.c_uint32, P(C.c_uint64 * 4)]
     lib.mipt_load_test_model.argtypes = [C.c_int, vp, C.c_size_t]
     lib.mipt_default_camera.argtypes = [P(MiptCamera), C.c_int]
     lib.mipt_default_camera.restype = None

@@ -155,6 +155,14 @@ class Scene:
                                           _ptr(px), _ptr(py), _ptr(sample), n, _ptr(rgb), _ptr(counts)))
         return rgb, counts
 
+    def selfcheck(self, n_rays, seed=0):
+        """Device-side comparison of the fast arithmetic with the literal reference arithmetic:
+        returns (reciprocal mismatches over all 2^32 floats, worst hardware-reciprocal error in ulp,
+        closest-hit mismatches, any-hit mismatches) for n_rays generated rays."""
+        out = (C.c_uint64 * 4)()
+        _check(self._lib.mipt_debug_selfcheck(self._h, n_rays, seed, C.byref(out)))
+        return int(out[0]), out[1] / 1024.0, int(out[2]), int(out[3])
+
     def stats(self):
         s = abi.MiptStats()
         _check(self._lib.mipt_get_stats(self._h, C.byref(s)))

@@ -49,6 +49,7 @@ struct MiptScene {
   ShadeRec* d_shade = nullptr;
   SphereRec* d_spheres = nullptr;
   unsigned long long* d_stats = nullptr;
+  uint32_t* d_queue = nullptr;
   float* d_partial = nullptr;
   size_t partial_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -64,6 +65,7 @@ static void scene_free(MiptScene* s) {
   if (s->d_shade) (void)hipFree(s->d_shade);
   if (s->d_spheres) (void)hipFree(s->d_spheres);
   if (s->d_stats) (void)hipFree(s->d_stats);
+  if (s->d_queue) (void)hipFree(s->d_queue);
   if (s->d_partial) (void)hipFree(s->d_partial);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -115,6 +117,7 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
   HIP_TRY(hipMalloc(&s->d_shade, sh.size() * sizeof(ShadeRec)));
   HIP_TRY(hipMalloc(&s->d_spheres, sp.size() * sizeof(SphereRec)));
   HIP_TRY(hipMalloc(&s->d_stats, ST_COUNT * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&s->d_queue, 256));
   HIP_TRY(hipMemcpy(s->d_tris, tr.data(), tr.size() * sizeof(TriRec), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s->d_shade, sh.data(), sh.size() * sizeof(ShadeRec), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s->d_spheres, sp.data(), sp.size() * sizeof(SphereRec), hipMemcpyHostToDevice));
@@ -316,20 +319,19 @@ extern "C" int mipt_render_accumulate_dev(MiptScene* s, const MiptCamera* cam, c
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
 
-  const uint32_t tiles_x = (uint32_t)((p->width + TILE_X - 1) / TILE_X);
-  const uint32_t tiles_y = (uint32_t)((p->height + TILE_Y - 1) / TILE_Y);
-  const uint32_t pixel_blocks = tiles_x * tiles_y;
-  // many more blocks than the chip has slots, but at least 32 samples per chunk
-  uint32_t n_chunks = (65536u + pixel_blocks - 1) / pixel_blocks;
-  uint32_t max_chunks = sample_count / 32u;
-  if (max_chunks < 1) max_chunks = 1;
-  if (n_chunks > max_chunks) n_chunks = max_chunks;
-  if (n_chunks > 65535u) n_chunks = 65535u;
-  const uint32_t chunk = (sample_count + n_chunks - 1) / n_chunks;
-  n_chunks = (sample_count + chunk - 1) / chunk;
+  // work items: ITEM_SAMPLES consecutive samples of one pixel, enumerated tile by tile (8x8
+  // pixels) and sample block by sample block; one scratch image per sample block
+  const uint32_t tiles_x = (uint32_t)((p->width + 7) / 8), tiles_y = (uint32_t)((p->height + 7) / 8);
+  const uint64_t n_slots = (uint64_t)tiles_x * tiles_y * 64u;
+  const uint32_t item_samples = sample_count < ITEM_SAMPLES ? sample_count : ITEM_SAMPLES;
+  const uint32_t n_sblocks = (sample_count + item_samples - 1) / item_samples;
+  const uint64_t n_items = n_slots * n_sblocks;
+  if (n_items >= 0xFF000000ull)
+    return fail(MIPT_E_INVALID, "mipt_render_accumulate: %llu work items in one call; render fewer samples per call",
+                (unsigned long long)n_items);
 
   const size_t n_img = (size_t)p->width * p->height * 3;
-  const size_t need = n_img * sizeof(float) * n_chunks;
+  const size_t need = n_img * sizeof(float) * n_sblocks;
   if (need > s->partial_bytes) {
     // the scratch image stack is kept with the scene and only ever grows
     HIP_TRY(hipStreamSynchronize(st));
@@ -342,16 +344,23 @@ extern "C" int mipt_render_accumulate_dev(MiptScene* s, const MiptCamera* cam, c
   fill_args(a, s, cam, light, p);
   a.sample_begin = sample_begin;
   a.sample_count = sample_count;
-  a.chunk = chunk;
+  a.item_samples = item_samples;
   a.tiles_x = tiles_x;
+  a.n_slots = (uint32_t)n_slots;
+  a.n_items = (uint32_t)n_items;
+  a.queue = s->d_queue;
   a.partial = s->d_partial;
+  // enough resident waves to fill the chip at any occupancy; every lane loops over the queue
+  const uint64_t batches = n_items / 64u;
+  const unsigned grid = (unsigned)(batches / 4u + 1u < PERSISTENT_BLOCKS ? batches / 4u + 1u : PERSISTENT_BLOCKS);
+  HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(uint32_t), st));
   const bool stats = (p->flags & MIPT_FLAG_STATS) != 0;
   if (stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, ST_COUNT * sizeof(unsigned long long), st));
   HIP_TRY(hipEventRecord(s->ev0, st));
-  launch_paths<false>(a, dim3(pixel_blocks, n_chunks), stack_bytes(s, p), st);
+  launch_paths<false>(a, dim3(grid), stack_bytes(s, p), st);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev1, st));
-  hipLaunchKernelGGL(k_reduce_chunks, dim3(grid_for(n_img)), dim3(BLOCK), 0, st, s->d_partial, n_chunks, n_img,
+  hipLaunchKernelGGL(k_reduce_chunks, dim3(grid_for(n_img)), dim3(BLOCK), 0, st, s->d_partial, n_sblocks, n_img,
                      d_accum_rgb);
   HIP_TRY(hipGetLastError());
   s->timed = true;
@@ -473,6 +482,27 @@ extern "C" int mipt_resolve_argb(MiptScene* s, const float* accum_rgb, int width
   if (rc != MIPT_OK) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(screen_buffer, scr.p, n * 4, hipMemcpyDeviceToHost));
+  return MIPT_OK;
+}
+
+extern "C" int mipt_debug_selfcheck(MiptScene* s, uint64_t n_rays, uint32_t seed, uint64_t out[4]) {
+  if (!s || !out) return fail(MIPT_E_INVALID, "mipt_debug_selfcheck: null argument");
+  if (n_rays > ((uint64_t)1 << 36)) return fail(MIPT_E_INVALID, "mipt_debug_selfcheck: at most 2^36 rays per call");
+  HIP_TRY(hipSetDevice(s->device));
+  DevBuf d;
+  HIP_TRY(d.alloc(4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(d.p, 0, 4 * sizeof(unsigned long long)));
+  hipLaunchKernelGGL(k_selfcheck_rcp, dim3(4096 / BLOCK), dim3(BLOCK), 0, nullptr, d.as<unsigned long long>());
+  HIP_TRY(hipGetLastError());
+  if (n_rays) {
+    hipLaunchKernelGGL(k_selfcheck_scan, dim3((unsigned)((n_rays + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, nullptr, s->d,
+                       (unsigned long long)n_rays, seed, d.as<unsigned long long>());
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long h[4];
+  HIP_TRY(hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 4; ++i) out[i] = h[i];
   return MIPT_OK;
 }
 

@@ -215,9 +215,37 @@ struct HitAcc {
   float lim;  // closest: minimumDistance; shadow: inter.distance, -1 once occluded
   int idx;    // closest: winning primitive, -1 = none; shadow: 1 = occluded
   float by, bz;  // barycentrics x.y, x.z of the winning triangle
+  float lim_lo, lim_hi;  // lim * (1 -/+ 2^-20): the band inside which the gate needs the exact quotient
+
+  __device__ __forceinline__ void set_lim(float v) {
+    lim = v;
+    lim_lo = v * 0.99999904632568359375f;  // 1 - 2^-20
+    lim_hi = v * 1.00000095367431640625f;  // 1 + 2^-20
+  }
 };
 
-template <bool STATS>
+// Correctly rounded 1/b. Fast path: hardware reciprocal estimate (<= 1 ulp) + two Newton steps in
+// fused arithmetic; it equals IEEE 1.0f/b for every b with 2^-100 <= |b| <= 2^100 (checked
+// exhaustively on the GPU by mipt_debug_selfcheck). Anything else (zero, subnormal, huge, inf,
+// NaN) takes the IEEE division. r0 is the caller's estimate v_rcp_f32(b).
+__device__ __forceinline__ float rcp_exact(float b, float r0) {
+  const float ab = fabsf(b);
+  if (ab >= 7.888609052210118e-31f && ab <= 1.2676506002282294e30f) {
+    float e = __builtin_fmaf(-b, r0, 1.0f);
+    float r = __builtin_fmaf(e, r0, r0);
+    e = __builtin_fmaf(-b, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+  }
+  return 1.0f / b;
+}
+
+// One triangle of the scan. FAST = false is the literal reference arithmetic. FAST = true decides
+// the gate `t >= 0 && t <= lim` (t = detM / detA, used for nothing else) from the estimate
+// detM * rcp(detA) whenever that estimate is outside a relative band of 2^-20 around 0 and lim --
+// the estimate is within 3e-7 of the rounded quotient -- and computes the IEEE quotient only
+// inside the band; the reciprocal of the inverse path comes from rcp_exact. Same decisions, same
+// stored bits, ~20 fewer instructions per test.
+template <bool STATS, bool FAST>
 __device__ __forceinline__ void tri_test(const TriRec MIPT_CONST* __restrict__ T, int i, float ox,
                                          float oy, float oz, float px, float py, float pz,
                                          bool shadow, HitAcc& h, uint32_t& n_tests, uint32_t& n_gate) {
@@ -235,11 +263,27 @@ __device__ __forceinline__ void tri_test(const TriRec MIPT_CONST* __restrict__ T
   const float k1 = py * e2z - e2y * pz;
   const float k2 = py * e1z - e1y * pz;
   const float detA = ((px * c0) - (e1x * k1)) + (e2x * k2);
-  const float t = detM / detA;  // :23
-  if (t >= 0.0f && t <= h.lim) {  // :25 / :75
+  bool pass;
+  float r0 = 0.f;
+  if (FAST) {
+    r0 = __builtin_amdgcn_rcpf(detA);
+    const float qa = detM * r0;
+    const bool pos = qa >= 1e-30f && qa <= 1e30f;  // finite and clearly positive
+    const bool sure_pass = pos && qa <= h.lim_lo;
+    const bool sure_fail = (qa <= -1e-30f && qa >= -1e30f) || (pos && qa >= h.lim_hi);
+    pass = sure_pass;
+    if (!sure_pass && !sure_fail) {
+      const float t = detM / detA;  // :23
+      pass = t >= 0.0f && t <= h.lim;
+    }
+  } else {
+    const float t = detM / detA;  // :23
+    pass = t >= 0.0f && t <= h.lim;  // :25 / :75
+  }
+  if (pass) {
     if (STATS) n_gate++;
     // glm::inverse(A) * b (:26): type_mat3x3.inl:39-53 then :510-512
-    const float ood = 1.0f / detA;
+    const float ood = FAST ? rcp_exact(detA, r0) : 1.0f / detA;
     const float i00 = c0 * ood;
     const float i10 = -(T->c1) * ood;
     const float i20 = T->c2 * ood;
@@ -257,10 +301,10 @@ __device__ __forceinline__ void tri_test(const TriRec MIPT_CONST* __restrict__ T
     const float bound = shadow ? 1.0f : __uint_as_float(0x3F8020C4u);
     if (x1 >= 0.0f && x2 >= 0.0f && (x1 + x2) <= bound) {
       if (shadow) {
-        h.lim = -1.0f;  // `break` (:79): no later triangle can pass t >= 0 && t <= -1
+        h.set_lim(-1.0f);  // `break` (:79): no later triangle can pass t >= 0 && t <= -1
         h.idx = 1;
       } else {
-        h.lim = fabsf(x0);  // :28
+        h.set_lim(fabsf(x0));  // :28
         h.idx = i;
         h.by = x1;
         h.bz = x2;

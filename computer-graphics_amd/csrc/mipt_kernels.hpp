@@ -16,10 +16,12 @@
 namespace mipt {
 
 constexpr int BLOCK = 256;
-// a block renders an 8 (x) by 32 (y) pixel tile; each wave an 8 x 8 tile. y runs fastest in
-// the accumulation buffer (x-major, like the reference's pixels[x][y]).
-constexpr int TILE_X = 8;
-constexpr int TILE_Y = 32;
+// samples per work item of the path kernel, and the size of its persistent grid (256 CUs x 8)
+#ifndef MIPT_ITEM_SAMPLES
+#define MIPT_ITEM_SAMPLES 16
+#endif
+constexpr uint32_t ITEM_SAMPLES = MIPT_ITEM_SAMPLES;
+constexpr uint32_t PERSISTENT_BLOCKS = 2048;
 
 constexpr uint32_t TAG_GLASS = 0xFFFFFFFEu;
 constexpr uint32_t TAG_FOG = 0xFFFFFFFDu;
@@ -34,9 +36,12 @@ struct PathArgs {
   MiptParams p;
   uint32_t sample_begin;
   uint32_t sample_count;
-  uint32_t chunk;  // samples per chunk; gridDim.y chunks
-  uint32_t tiles_x;
-  float* partial;  // [gridDim.y][W*H*3]
+  uint32_t item_samples;  // samples per work item
+  uint32_t tiles_x;       // 8x8 pixel tiles per image row
+  uint32_t n_slots;       // tiles * 64 (pixel slots incl. padding of ragged image sizes)
+  uint32_t n_items;       // n_slots * sample blocks
+  uint32_t* queue;        // head of the work queue, zeroed before the launch
+  float* partial;         // [sample block][W*H*3] per-item radiance sums
   // list mode (mipt_trace_paths)
   const int32_t* px;
   const int32_t* py;
@@ -49,13 +54,17 @@ struct PathArgs {
 
 // ---------------------------------------------------------------------------------------
 
-template <bool STATS>
+#ifndef MIPT_SCAN_FAST
+#define MIPT_SCAN_FAST 1
+#endif
+
+template <bool STATS, bool FAST = (MIPT_SCAN_FAST != 0)>
 __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d, bool shadow, HitAcc& h,
                                                uint32_t& n_tests, uint32_t& n_gate) {
   const TriRec MIPT_CONST* tris = as_constant(sc.tris);
   const float px = -d.x, py = -d.y, pz = -d.z;  // vec3(-ray.direction), intersections.cpp:20
   const int n = sc.n_tris;
-  for (int i = 0; i < n; ++i) tri_test<STATS>(tris + i, i, o.x, o.y, o.z, px, py, pz, shadow, h, n_tests, n_gate);
+  for (int i = 0; i < n; ++i) tri_test<STATS, FAST>(tris + i, i, o.x, o.y, o.z, px, py, pz, shadow, h, n_tests, n_gate);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_closest_hit(DeviceScene sc, const float4* __restrict__ origin,
@@ -66,7 +75,9 @@ __global__ __launch_bounds__(BLOCK) void k_closest_hit(DeviceScene sc, const flo
   if (i >= n_rays) return;
   const float4 of = origin[i], df = dir[i];
   const V4 o = {of.x, of.y, of.z, of.w}, d = {df.x, df.y, df.z, df.w};
-  HitAcc h = {3.402823466e+38f, -1, 0.f, 0.f};
+  HitAcc h;
+  h.set_lim(3.402823466e+38f);
+  h.idx = -1; h.by = 0.f; h.bz = 0.f;
   uint32_t n_tests = 0, n_gate = 0;
   scan_triangles<false>(sc, o, d, false, h, n_tests, n_gate);
   V4 pos = {0, 0, 0, 0}, nrm;
@@ -101,7 +112,9 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
   if (i >= n_rays) return;
   const float4 of = origin[i], df = dir[i];
   const V4 o = {of.x, of.y, of.z, of.w}, d = {df.x, df.y, df.z, df.w};
-  HitAcc h = {max_t[i], 0, 0.f, 0.f};
+  HitAcc h;
+  h.set_lim(max_t[i]);
+  h.idx = 0; h.by = 0.f; h.bz = 0.f;
   uint32_t n_tests = 0, n_gate = 0;
   scan_triangles<false>(sc, o, d, true, h, n_tests, n_gate);
   occluded[i] = (uint8_t)h.idx;
@@ -110,15 +123,17 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
 // ---------------------------------------------------------------------------------------
 // The path kernel.
 //
-// One lane owns one pixel and walks its samples in order, so a pixel's radiance sum is formed
-// in sample order by one lane and written with a plain store: no atomics, deterministic image.
+// Persistent lanes over a global work queue. A work item is a run of ITEM_SAMPLES consecutive
+// samples of one pixel; a lane adds the item's path radiances in sample order and stores the sum
+// to the item's own slot of a scratch image stack, so the image is deterministic (no float
+// atomics) whichever lane ran which item; k_reduce_chunks then adds the item sums of a pixel
+// in sample order. Path lengths vary from 1 ray (camera ray misses the box) to 20, so lanes
+// that finish an item draw the next one from the queue instead of waiting for their neighbours.
 // The reference's recursion (trace -> bounce* -> trace ...) is single-child, so it is run as a
 // loop with one ray/scene query per iteration. A lane whose path ended starts its next sample
 // in the same iteration ("regeneration"), and a terminal vertex turns the lane's next query
 // into the shadow ray of directLight, handled by the same triangle scan with the any-hit
-// rule -- the scan, ~90 % of the work, therefore always runs with every unfinished lane of
-// the wave active. Samples are split over gridDim.y chunks so that the grid has many more
-// blocks than the chip has slots; chunk images are summed in chunk order by k_reduce_chunks.
+// rule -- the scan, most of the work, therefore runs with every lane of the wave active.
 //
 // pathtracer.cpp passes `Ray&` down the recursion, and bounceDiffuse reads ray.direction AFTER
 // the recursive call returns (pathtracer.cpp:17-18): the cosine factor of every diffuse vertex
@@ -126,11 +141,12 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
 // applied when the path ends, deepest vertex first, from a small per-lane stack of primitive
 // tags kept in LDS.
 
-#ifdef MIPT_WAVES_PER_EU
-#define MIPT_PATHS_OCC __attribute__((amdgpu_waves_per_eu(MIPT_WAVES_PER_EU, MIPT_WAVES_PER_EU)))
-#else
-#define MIPT_PATHS_OCC
+// Register budget of the path kernel: 5 waves per SIMD (<= 96 VGPRs) measured fastest on the
+// fog-on Cornell workload (4: -8 %, 6: -2 %); the compiler's own choice (3-4 waves) is slower.
+#ifndef MIPT_WAVES_PER_EU
+#define MIPT_WAVES_PER_EU 5
 #endif
+#define MIPT_PATHS_OCC __attribute__((amdgpu_waves_per_eu(MIPT_WAVES_PER_EU, MIPT_WAVES_PER_EU)))
 
 template <int RNG_MODE, bool STATS, bool LIST>
 __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a) {
@@ -139,29 +155,25 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   const MiptParams& P = a.p;
   const int W = P.width, H = P.height;
 
+  // work of the lane: a run of samples [s, s_end) of pixel (x, y). LIST: the one listed path.
+  // Otherwise an item drawn from the global queue (see the loop head).
+  const int lane = tid & 63;
   int x = 0, y = 0;
-  uint32_t s = 0, s_end = 0;
+  uint32_t s = 0, s_end = 0, pixel = 0;
   size_t list_i = 0;
+  float* dst = nullptr;
+  bool have = false;
   if (LIST) {
     list_i = (size_t)blockIdx.x * BLOCK + tid;
     if (list_i < a.n_paths) {
       x = a.px[list_i]; y = a.py[list_i];
       s = a.samp[list_i]; s_end = s + 1;
-    }
-  } else {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
-    x = tx * TILE_X + (lane >> 3);
-    y = ty * TILE_Y + wave * 8 + (lane & 7);
-    if (x < W && y < H) {
-      s = a.sample_begin + blockIdx.y * a.chunk;
-      const uint32_t last = a.sample_begin + a.sample_count;
-      s_end = (s + a.chunk < last) ? s + a.chunk : last;
-      if (s > s_end) s = s_end;
+      pixel = (uint32_t)(x * H + y);
+      have = true;
     }
   }
-  const uint32_t pixel = (uint32_t)(x * H + y);
-  bool active = s < s_end;
+  uint32_t res_next = 0, res_end = 0;  // wave-uniform: the items of the last batch not handed out yet
+  bool drained = LIST;                 // wave-uniform: the queue has nothing left
 
   float sum_r = 0.f, sum_g = 0.f, sum_b = 0.f;
   uint32_t st[ST_COUNT];
@@ -181,7 +193,56 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   float* sph_n = reinterpret_cast<float*>(lds_stack + (size_t)P.max_depth * BLOCK);
   const bool fog = P.fog_sigma_t > 0.f;
 
-  while (active) {
+  for (;;) {
+    if (!LIST) {
+      // Work distribution. An item is ITEM_SAMPLES consecutive samples of one pixel; item ids run
+      // over 8x8 pixel tiles, sample block by sample block. A wave draws 64 ids (one tile) at a
+      // time with ONE atomic on the queue head and hands them to its lanes as they run dry, so
+      // every lane stays busy until the whole frame is done -- however uneven the path lengths.
+      const unsigned long long need = __ballot(!have);
+      if (need && !drained) {
+        if (res_next == res_end) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(a.queue, 64u);
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (base >= a.n_items) {
+            drained = true;
+          } else {
+            res_next = base;
+            res_end = base + 64u;  // n_items is a multiple of 64
+          }
+        }
+        if (!drained) {
+          const uint32_t avail = res_end - res_next;
+          const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+          if (!have && rank < avail) {
+            const uint32_t item = res_next + rank;
+            const uint32_t sb = item / a.n_slots, slot = item - sb * a.n_slots;
+            const uint32_t tile = slot >> 6, l = slot & 63u;
+            const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+            x = (int)(tx * 8u + (l >> 3));
+            y = (int)(ty * 8u + (l & 7u));
+            if (x < W && y < H) {
+              pixel = (uint32_t)(x * H + y);
+              s = a.sample_begin + sb * a.item_samples;
+              const uint32_t last = a.sample_begin + a.sample_count;
+              s_end = (s + a.item_samples < last) ? s + a.item_samples : last;
+              dst = a.partial + ((size_t)sb * ((size_t)W * H) + pixel) * 3;
+              sum_r = 0.f; sum_g = 0.f; sum_b = 0.f;
+              fresh = true;
+              have = true;
+            }
+          }
+          const uint32_t n_need = (uint32_t)__popcll(need);
+          res_next += (n_need < avail) ? n_need : avail;
+        }
+      }
+    }
+    if (!__any(have)) {
+      if (drained) break;
+      continue;
+    }
+    if (have) {
     if (fresh) {
       // main.cpp:124-133: two draws jitter the pixel, direction = Rx*Ry*d, not normalised
       rng_begin<RNG_MODE>(rng, P.seed, pixel, s);
@@ -202,7 +263,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
 
     // ---- one ray/scene query: closestIntersection, or existsIntersection for a shadow ray
     HitAcc h;
-    h.lim = shadow ? shadow_max : 3.402823466e+38f;
+    h.set_lim(shadow ? shadow_max : 3.402823466e+38f);
     h.idx = shadow ? 0 : -1;
     h.by = 0.f; h.bz = 0.f;
     uint32_t n_tests = 0, n_gate = 0;
@@ -413,8 +474,13 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       }
       s++;
       fresh = true;
-      active = s < s_end;
+      if (s >= s_end) {
+        // the item's samples were added in sample order by this one lane: plain store
+        have = false;
+        if (!LIST) { dst[0] = sum_r; dst[1] = sum_g; dst[2] = sum_b; }
+      }
     }
+    }  // if (have)
   }
 
   if (LIST) {
@@ -422,9 +488,6 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       a.rgb[3 * list_i + 0] = sum_r; a.rgb[3 * list_i + 1] = sum_g; a.rgb[3 * list_i + 2] = sum_b;
       if (a.counts) { a.counts[2 * list_i] = st[ST_CLOSEST]; a.counts[2 * list_i + 1] = st[ST_SHADOW]; }
     }
-  } else if (x < W && y < H) {
-    float* dst = a.partial + (size_t)blockIdx.y * ((size_t)W * H * 3) + (size_t)pixel * 3;
-    dst[0] = sum_r; dst[1] = sum_g; dst[2] = sum_b;
   }
 
   if (STATS) {
@@ -435,6 +498,76 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
       if ((tid & 63) == 0 && v) atomicAdd(a.stats + k, v);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Device-side self-check of the fast arithmetic against the literal one, at sizes no CPU oracle
+// can reach. out[0]: floats b (all 2^32 bit patterns) whose rcp_exact differs from IEEE 1.0f/b;
+// out[1]: largest error of the hardware estimate v_rcp_f32, in units of 2^-10 ulp, over the
+// fast-path range; out[2] / out[3]: generated rays whose FAST scan result (index, distance,
+// barycentrics) differs from the literal scan, closest-hit / any-hit rule.
+
+__global__ __launch_bounds__(BLOCK) void k_selfcheck_rcp(unsigned long long* out) {
+  const uint32_t stride = gridDim.x * BLOCK;
+  uint32_t bad = 0, worst = 0;
+  uint32_t bits = blockIdx.x * BLOCK + threadIdx.x;
+  for (uint32_t it = 0; it < (1u << 20); ++it, bits += stride) {  // gridDim.x * BLOCK == 2^12
+    const float b = __uint_as_float(bits);
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float fast = rcp_exact(b, r0);
+    const float ref = 1.0f / b;
+    const bool same = (__float_as_uint(fast) == __float_as_uint(ref)) || (fast != fast && ref != ref);
+    bad += same ? 0u : 1u;
+    const float ab = fabsf(b);
+    if (ab >= 7.888609052210118e-31f && ab <= 1.2676506002282294e30f) {
+      const double exact = 1.0 / (double)b;
+      const double ulp = (double)__uint_as_float((__float_as_uint(ref) & 0x7F800000u)) * 1.1920928955078125e-7;
+      const double err = fabs((double)r0 - exact) / ulp;
+      const uint32_t q = (uint32_t)(err * 1024.0);
+      worst = q > worst ? q : worst;
+    }
+  }
+  if (bad) atomicAdd(out + 0, (unsigned long long)bad);
+  atomicMax(out + 1, (unsigned long long)worst);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_selfcheck_scan(DeviceScene sc, unsigned long long n_rays, uint32_t seed,
+                                                          unsigned long long* out) {
+  const unsigned long long gid = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (gid >= n_rays) return;
+  // ray generator: four families chosen by the low bits of the ray number
+  uint32_t k = path_key(seed, (uint32_t)gid, (uint32_t)(gid >> 32));
+  auto u01 = [&]() { k = mix32(k + 0x9E3779B9u); return (float)(k >> 8) * (1.0f / 16777216.0f); };
+  V4 o, d;
+  const int family = (int)(gid & 3);
+  if (family == 0) {  // camera rays of a 1024^2 frame, direction not normalised
+    o = {0.f, 0.f, -3.f, 1.f};
+    d = {(u01() - 0.5f) * 1024.f, (u01() - 0.5f) * 1024.f, 1024.f, 0.f};
+  } else {
+    if (family == 1 || sc.n_tris == 0) {  // incoherent rays from inside the box
+      o = {u01() * 1.9f - 0.95f, u01() * 1.9f - 0.95f, u01() * 1.9f - 0.95f, 1.f};
+    } else {  // origin exactly on a triangle (family 2) or exactly on one of its edges (family 3)
+      const TriRec T = sc.tris[(uint32_t)(u01() * (float)sc.n_tris) % (uint32_t)sc.n_tris];
+      float a = u01(), b = u01() * (1.0f - a);
+      if (family == 3) b = 0.f;
+      o = {(T.v0x + a * T.e1x) + b * T.e2x, (T.v0y + a * T.e1y) + b * T.e2y, (T.v0z + a * T.e1z) + b * T.e2z, 1.f};
+    }
+    const float z = 1.0f - 2.0f * u01(), phi = 6.2831853f * u01();
+    const float rxy = sqrtf(fmaxf(0.f, 1.0f - z * z));
+    d = normalize4({rxy * cosf(phi), rxy * sinf(phi), z, 1.0f});
+  }
+  const float max_t = u01() * 2.5f;
+  for (int mode = 0; mode < 2; ++mode) {
+    HitAcc f, e;
+    f.set_lim(mode ? max_t : 3.402823466e+38f); f.idx = mode ? 0 : -1; f.by = f.bz = 0.f;
+    e = f;
+    uint32_t nt = 0, ng = 0;
+    scan_triangles<false, true>(sc, o, d, mode != 0, f, nt, ng);
+    scan_triangles<false, false>(sc, o, d, mode != 0, e, nt, ng);
+    const bool same = f.idx == e.idx && __float_as_uint(f.lim) == __float_as_uint(e.lim) &&
+                      __float_as_uint(f.by) == __float_as_uint(e.by) && __float_as_uint(f.bz) == __float_as_uint(e.bz);
+    if (!same) atomicAdd(out + 2 + mode, 1ull);
   }
 }
 

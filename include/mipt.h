@@ -219,6 +219,15 @@ int mipt_resolve_argb_dev(MiptScene* scene, const float* d_accum_rgb, int width,
  * stream; synchronises that stream). */
 int mipt_get_stats(MiptScene* scene, MiptStats* out);
 
+/* Self-check with no counterpart in the reference: runs on the GPU (1) the library's fast
+ * correctly-rounded reciprocal against IEEE 1.0f/b for all 2^32 floats and (2) its fast triangle
+ * scan against the literal reference arithmetic on n_rays generated rays (camera rays, incoherent
+ * interior rays, origins on triangle surfaces and edges), closest-hit and any-hit rule.
+ * out[0] = reciprocal mismatches, out[1] = worst error of the hardware reciprocal estimate in
+ * 2^-10 ulp, out[2] / out[3] = rays whose closest-hit / any-hit result differs. All of
+ * out[0], out[2], out[3] must be 0. */
+int mipt_debug_selfcheck(MiptScene* scene, uint64_t n_rays, uint32_t seed, uint64_t out[4]);
+
 /* The (seed, pixel, sample) -> 32-bit key shared by both per-path RNG modes.
  * pixel = x*height + y. Exposed so that hosts and tests can reproduce streams. */
 uint32_t mipt_path_key(uint32_t seed, uint32_t pixel, uint32_t sample);

@@ -55,6 +55,20 @@ def test_closest_hit_bit_exact(api, O, scene):
             assert (idx >= 0).mean() > 0.3, name
 
 
+@pytest.mark.parametrize("scene", ["cornell", "glasscube"])
+def test_fast_scan_equals_literal_scan_at_scale(api, O, scene):
+    # full-size property check on the device: the shipped scan (estimate-based gate, fast exact
+    # reciprocal) against the literal reference arithmetic on 2^30 generated rays, and the fast
+    # reciprocal against IEEE division for every float
+    tris = O.load_test_model(SCENES[scene][0])
+    sc = api.Scene(tris)
+    rcp_bad, rcp_err_ulp, closest_bad, any_bad = sc.selfcheck(1 << 30, seed=123)
+    sc.close()
+    assert rcp_bad == 0
+    assert rcp_err_ulp <= 1.0, rcp_err_ulp   # the gate's band of 2^-20 assumes an estimate good to ~1 ulp
+    assert closest_bad == 0 and any_bad == 0, (closest_bad, any_bad)
+
+
 def test_closest_hit_with_sphere(api, O):
     tris = O.load_test_model(2)
     sph = api.make_sphere(0.3, [-0.45, 0.7, -0.55, 1], [1, 0, 0])  # main.cpp:75
