@@ -96,10 +96,29 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
     volatile float a1 = e1x * e2z, b1 = e2x * e1z;
     volatile float a2 = e1x * e2y, b2 = e2x * e1y;
     r.c0 = a0 - b0; r.c1 = a1 - b1; r.c2 = a2 - b2;
+    // error-bound factors of the candidate filter (tri_candidate); a triangle whose magnitudes
+    // leave the range the bounds were derived for is marked "never reject"
+    const float E1 = std::fmax(std::fmax(std::fabs(r.e1x), std::fabs(r.e1y)), std::fabs(r.e1z));
+    const float E2 = std::fmax(std::fmax(std::fabs(r.e2x), std::fabs(r.e2y)), std::fabs(r.e2z));
+    const float V0 = std::fmax(std::fmax(std::fabs(r.v0x), std::fabs(r.v0y)), std::fabs(r.v0z));
+    const bool sane = E1 >= 9.094947e-13f && E1 <= 1.0995116e12f && E2 >= 9.094947e-13f && E2 <= 1.0995116e12f &&
+                      V0 <= 1.0995116e12f;  // [2^-40, 2^40]; NaN fails
+    r.kA = sane ? 0.000244140625f * (E1 * E2) : INFINITY;      // 2^-12
+    r.kB = sane ? 7.62939453125e-06f * std::fmax(E1, E2) : 0.f;  // 2^-17
+    r.kT = sane ? 7.62939453125e-06f * (E1 * E2) : 0.f;
     ShadeRec& q = sh[i];
     q.nx = t.normal[0]; q.ny = t.normal[1]; q.nz = t.normal[2]; q.nw = t.normal[3];
     q.r = t.color[0]; q.g = t.color[1]; q.b = t.color[2];
     q.material = t.material;
+    // constants of the normal (this file is compiled with -ffp-contract=off: same bits as on the device)
+    const V4 n4 = {q.nx, q.ny, q.nz, q.nw};
+    const V4 nn = normalize4(n4);
+    V3 nt, nb;
+    orthonormal_system(n4, nt, nb);
+    q.nnx = nn.x; q.nny = nn.y; q.nnz = nn.z; q.nnw = nn.w;
+    q.ntx = nt.x; q.nty = nt.y; q.ntz = nt.z;
+    q.nbx = nb.x; q.nby = nb.y; q.nbz = nb.z;
+    q.pad0 = q.pad1 = 0.f;
   }
   for (size_t j = 0; j < n_spheres; ++j) {
     const MiptSphere& u = spheres[j];
@@ -284,6 +303,15 @@ static void fill_args(PathArgs& a, const MiptScene* s, const MiptCamera* cam, co
   a.focal = cam->focal;
   memcpy(a.light_pos, light->pos, sizeof a.light_pos);
   memcpy(a.light_col, light->color, sizeof a.light_col);
+  a.light_gray = (light->color[0] == light->color[1] && light->color[1] == light->color[2]) ? 1u : 0u;
+  {
+    volatile float num = p->ior_air - p->ior_glass, den = p->ior_air + p->ior_glass;
+    volatile float r0 = num / den;
+    a.glass_R0 = r0 * r0;
+    volatile float inv = 1.0f / p->ior_glass;
+    a.eta_enter = inv;
+    a.eta_exit = 1.0f / inv;
+  }
   a.p = *p;
   a.stats = s->d_stats;
 }

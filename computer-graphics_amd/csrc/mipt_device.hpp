@@ -25,18 +25,28 @@ namespace mipt {
 //   c1 = e1.x*e2.z - e2.x*e1.z               first-column cofactors of glm::determinant
 //   c2 = e1.x*e2.y - e2.x*e1.y               (func_matrix.inl:235-238) and first row of
 //                                            glm::inverse (type_mat3x3.inl:45-47)
+//   kA, kB, kT                               error-bound factors of the candidate filter
+//                                            (tri_candidate): 2^-12 |e1|oo |e2|oo,
+//                                            2^-17 max(|e1|oo, |e2|oo), 2^-17 |e1|oo |e2|oo;
+//                                            kA = +inf marks a triangle the filter never rejects
 struct __attribute__((aligned(64))) TriRec {
   float v0x, v0y, v0z, v0w;
   float e1x, e1y, e1z, c0;
   float e2x, e2y, e2z, c1;
-  float c2, pad0, pad1, pad2;
+  float c2, kA, kB, kT;
 };
 
-// ShadeRec: what shading needs about the ONE primitive a ray hit; gathered per lane.
+// ShadeRec: what shading needs about the ONE primitive a ray hit; gathered per lane. For
+// triangles the normal is constant, so everything the path computes from the normal alone is
+// computed once on the host with the same IEEE operations: nn = normalize(normal) (light.cpp:20)
+// and (nt, nb) = orthonormalSystem(normal) (utils.cpp:16-22). Sphere records leave them zero.
 struct __attribute__((aligned(32))) ShadeRec {
   float nx, ny, nz, nw;
   float r, g, b;
   uint32_t material;
+  float nnx, nny, nnz, nnw;
+  float ntx, nty, ntz, nbx;
+  float nby, nbz, pad0, pad1;
 };
 
 struct __attribute__((aligned(16))) SphereRec {
@@ -74,23 +84,35 @@ __device__ __forceinline__ const T MIPT_CONST* as_constant(const T* p) {
 struct V3 { float x, y, z; };
 struct V4 { float x, y, z, w; };
 
-__device__ __forceinline__ float dot3(V3 a, V3 b) {  // func_geometric.inl:69-70
+__host__ __device__ __forceinline__ float dot3(V3 a, V3 b) {  // func_geometric.inl:69-70
   float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
   return (tx + ty) + tz;
 }
-__device__ __forceinline__ float dot4(V4 a, V4 b) {  // func_geometric.inl:79-80
+__host__ __device__ __forceinline__ float dot4(V4 a, V4 b) {  // func_geometric.inl:79-80
   float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z, tw = a.w * b.w;
   return (tx + ty) + (tz + tw);
 }
-__device__ __forceinline__ V4 scale4(V4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
-__device__ __forceinline__ V4 add4(V4 a, V4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
-__device__ __forceinline__ V4 sub4(V4 a, V4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
-__device__ __forceinline__ V4 normalize4(V4 v) {  // func_geometric.inl:158, func_exponential.inl:66
+__host__ __device__ __forceinline__ V4 scale4(V4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+__host__ __device__ __forceinline__ V4 add4(V4 a, V4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+__host__ __device__ __forceinline__ V4 sub4(V4 a, V4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+__host__ __device__ __forceinline__ V4 normalize4(V4 v) {  // func_geometric.inl:158, func_exponential.inl:66
   float s = 1.0f / sqrtf(dot4(v, v));
   return scale4(v, s);
 }
-__device__ __forceinline__ V3 cross3(V3 x, V3 y) {  // func_geometric.inl:138-141
+__host__ __device__ __forceinline__ V3 cross3(V3 x, V3 y) {  // func_geometric.inl:138-141
   return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y};
+}
+
+// orthonormalSystem (utils.cpp:16-22): component-wise true division, then cross(N.xyz, Nt)
+__host__ __device__ inline void orthonormal_system(V4 n, V3& Nt, V3& Nb) {
+  if (fabsf(n.x) > fabsf(n.y)) {
+    const float len = sqrtf(n.x * n.x + n.z * n.z);
+    Nt = {n.z / len, 0.0f / len, -n.x / len};
+  } else {
+    const float len = sqrtf(n.y * n.y + n.z * n.z);
+    Nt = {0.0f / len, -n.z / len, n.y / len};
+  }
+  Nb = {n.y * Nt.z - Nt.y * n.z, n.z * Nt.x - Nt.z * n.x, n.x * Nt.y - Nt.x * n.y};
 }
 
 // ---------------------------------------------------------------------------------------
@@ -101,22 +123,30 @@ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
   return h;
 }
 
-__host__ __device__ inline uint32_t path_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
+// path_key(seed, pixel, sample) = sample_key(pixel_key(seed, pixel), sample); the pixel part is
+// computed once per work item, the sample part once per path.
+__host__ __device__ inline uint32_t pixel_key(uint32_t seed, uint32_t pixel) {
   uint32_t k = seed ^ 0x9E3779B9u;
   k ^= k >> 16; k *= 0x85EBCA6Bu; k ^= k >> 13; k *= 0xC2B2AE35u; k ^= k >> 16;
   k += pixel;
   k ^= k >> 16; k *= 0x85EBCA6Bu; k ^= k >> 13; k *= 0xC2B2AE35u; k ^= k >> 16;
-  k ^= (sample * 0x9E3779B1u + 0x7F4A7C15u);
+  return k;
+}
+__host__ __device__ inline uint32_t sample_key(uint32_t pkey, uint32_t sample) {
+  uint32_t k = pkey ^ (sample * 0x9E3779B1u + 0x7F4A7C15u);
   k ^= k >> 16; k *= 0x85EBCA6Bu; k ^= k >> 13; k *= 0xC2B2AE35u; k ^= k >> 16;
   return k;
+}
+__host__ __device__ inline uint32_t path_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
+  return sample_key(pixel_key(seed, pixel), sample);
 }
 
 // RNG_MODE MIPT_RNG_MINSTD_PATH: a = engine state.  MIPT_RNG_COUNTER: a = key, b = draw counter.
 struct Rng { uint32_t a, b; };
 
 template <int RNG_MODE>
-__device__ __forceinline__ void rng_begin(Rng& r, uint32_t seed, uint32_t pixel, uint32_t sample) {
-  uint32_t key = path_key(seed, pixel, sample);
+__device__ __forceinline__ void rng_begin(Rng& r, uint32_t pkey, uint32_t sample) {
+  uint32_t key = sample_key(pkey, sample);
   if (RNG_MODE == MIPT_RNG_COUNTER) {
     r.a = key; r.b = 0;
   } else {
@@ -239,16 +269,56 @@ __device__ __forceinline__ float rcp_exact(float b, float r0) {
   return 1.0f / b;
 }
 
+// Candidate filter of the two-phase scan: returns false only when the reference's test of this
+// triangle provably cannot accept, whatever the running minimum is. It evaluates the same
+// linear system by Moeller-Trumbore in fused arithmetic (u, v, t ~ x.y, x.z, t of the reference)
+// and rejects when the triangle is well conditioned for this ray AND (u, v) is outside the
+// accepted region or t is negative by more than an error bound:
+//   * every 3x3 determinant here and in the reference is a sum of six triple products, so either
+//     evaluation is within 32 eps M of the exact value, M = product of the operands' oo-norms
+//     (eps = 2^-24). "Well conditioned": |det| >= 2^12 eps |d|oo |e1|oo |e2|oo, which makes the
+//     two computed determinants agree in sign and to better than 1 %.
+//   * then |u - x.y| <= 0.02 + 2^-17 |s|oo |d|oo max(|e1|oo,|e2|oo) / |det| (same for v), and a
+//     quotient t below -(2^-17 |s|oo |e1|oo |e2|oo / |det| + 1e-30) means the reference's
+//     determinant ratio is negative and not rounded to zero.
+// NaNs, infinities and out-of-range magnitudes make every comparison false, i.e. "candidate".
+// Dm is |dir|oo, or +inf when the ray's magnitudes are outside [2^-40, 2^40].
+template <typename TP>
+__device__ __forceinline__ bool tri_candidate(TP T, float ox, float oy, float oz, float dx, float dy,
+                                              float dz, float Dm) {
+#pragma clang fp contract(fast)
+  const float sx = ox - T->v0x, sy = oy - T->v0y, sz = oz - T->v0z;
+  const float e1x = T->e1x, e1y = T->e1y, e1z = T->e1z;
+  const float e2x = T->e2x, e2y = T->e2y, e2z = T->e2z;
+  const float pvx = dy * e2z - dz * e2y, pvy = dz * e2x - dx * e2z, pvz = dx * e2y - dy * e2x;
+  const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+  const float un = sx * pvx + sy * pvy + sz * pvz;
+  const float qvx = sy * e1z - sz * e1y, qvy = sz * e1x - sx * e1z, qvz = sx * e1y - sy * e1x;
+  const float vn = dx * qvx + dy * qvy + dz * qvz;
+  const float tn = e2x * qvx + e2y * qvy + e2z * qvz;
+  const float S = fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz));
+  const bool well = fabsf(det) >= Dm * T->kA + 1e-35f;
+  const float inv = __builtin_amdgcn_rcpf(det);
+  const float ainv = fabsf(inv);
+  const float u = un * inv, v = vn * inv, t = tn * inv;
+  const float delta = ((S * Dm) * T->kB) * ainv + 0.02f;
+  const float dt = (S * T->kT) * ainv + 1e-30f;
+  const bool outside = (u < -delta) | (v < -delta) | (u + v > 1.001f + 2.0f * delta) | (t < -dt);
+  return !(well & outside);
+}
+
 // One triangle of the scan. FAST = false is the literal reference arithmetic. FAST = true decides
 // the gate `t >= 0 && t <= lim` (t = detM / detA, used for nothing else) from the estimate
 // detM * rcp(detA) whenever that estimate is outside a relative band of 2^-20 around 0 and lim --
 // the estimate is within 3e-7 of the rounded quotient -- and computes the IEEE quotient only
 // inside the band; the reciprocal of the inverse path comes from rcp_exact. Same decisions, same
 // stored bits, ~20 fewer instructions per test.
-template <bool STATS, bool FAST>
-__device__ __forceinline__ void tri_test(const TriRec MIPT_CONST* __restrict__ T, int i, float ox,
-                                         float oy, float oz, float px, float py, float pz,
-                                         bool shadow, HitAcc& h, uint32_t& n_tests, uint32_t& n_gate) {
+// T is a pointer to the record: through the constant address space when every lane tests the same
+// triangle (scalar loads), or to a lane-private copy when each lane tests its own candidate.
+template <bool STATS, bool FAST, typename TP>
+__device__ __forceinline__ void tri_test(TP T, int i, float ox, float oy, float oz, float px, float py,
+                                         float pz, bool shadow, HitAcc& h, uint32_t& n_tests,
+                                         uint32_t& n_gate) {
   // existsIntersection leaves its loop at the first accepted triangle (:79); the lane keeps
   // scanning here (its gate can no longer pass), so those iterations are not counted as tests
   if (STATS) n_tests += (shadow && h.idx) ? 0u : 1u;

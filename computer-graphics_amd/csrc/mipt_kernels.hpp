@@ -33,6 +33,10 @@ struct PathArgs {
   float focal;
   float light_pos[4];
   float light_col[3];
+  uint32_t light_gray;  // the three light channels are equal: one division instead of three
+  // bounceGlass constants (pathtracer.cpp:30-39), evaluated once on the host with the same IEEE
+  // operations: R0 = ((air - glass) / (air + glass))^2, 1/glass, 1/(1/glass)
+  float glass_R0, eta_enter, eta_exit;
   MiptParams p;
   uint32_t sample_begin;
   uint32_t sample_count;
@@ -54,17 +58,51 @@ struct PathArgs {
 
 // ---------------------------------------------------------------------------------------
 
-#ifndef MIPT_SCAN_FAST
-#define MIPT_SCAN_FAST 1
+// The linear scan of closestIntersection / existsIntersection, three ways with identical results:
+//   SCAN_LITERAL    the reference's arithmetic for every triangle, in index order;
+//   SCAN_FAST       the same with the estimate-based gate and rcp_exact (tri_test<FAST>);
+//   SCAN_TWO_PHASE  phase 1 runs the cheap candidate filter over all triangles (wave-uniform
+//                   records in SGPRs, every lane busy) and leaves each lane a bit mask of the few
+//                   triangles its ray can possibly hit; phase 2 lets every lane run the full test
+//                   on ITS OWN candidates, in index order. Triangles the filter rejects could not
+//                   have been accepted, and rejected tests never change the scan's state, so the
+//                   sequence of accepted triangles -- tie rule included -- is unchanged.
+enum ScanMode { SCAN_LITERAL = 0, SCAN_FAST = 1, SCAN_TWO_PHASE = 2 };
+
+#ifndef MIPT_SCAN_MODE
+#define MIPT_SCAN_MODE 2
 #endif
 
-template <bool STATS, bool FAST = (MIPT_SCAN_FAST != 0)>
+template <bool STATS, int MODE = (STATS ? SCAN_FAST : MIPT_SCAN_MODE)>
 __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d, bool shadow, HitAcc& h,
                                                uint32_t& n_tests, uint32_t& n_gate) {
   const TriRec MIPT_CONST* tris = as_constant(sc.tris);
   const float px = -d.x, py = -d.y, pz = -d.z;  // vec3(-ray.direction), intersections.cpp:20
   const int n = sc.n_tris;
-  for (int i = 0; i < n; ++i) tri_test<STATS, FAST>(tris + i, i, o.x, o.y, o.z, px, py, pz, shadow, h, n_tests, n_gate);
+  if (MODE != SCAN_TWO_PHASE) {
+    for (int i = 0; i < n; ++i)
+      tri_test<STATS, MODE == SCAN_FAST>(tris + i, i, o.x, o.y, o.z, px, py, pz, shadow, h, n_tests, n_gate);
+    return;
+  }
+  float Dm = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+  const float Om = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+  if (!(Dm >= 9.094947e-13f && Dm <= 1.0995116e12f && Om <= 1.0995116e12f)) Dm = __builtin_inff();
+  for (int base = 0; base < n; base += 32) {
+    const int m = (n - base < 32) ? n - base : 32;
+    uint32_t mask = 0;
+    for (int j = 0; j < m; ++j)
+      if (tri_candidate(tris + base + j, o.x, o.y, o.z, d.x, d.y, d.z, Dm)) mask |= 1u << j;
+    while (__any(mask != 0)) {
+      if (mask != 0) {
+        const int i = base + __ffs((int)mask) - 1;
+        mask &= mask - 1u;
+        // each lane fetches ITS candidate record (L1-resident for Cornell-sized scenes; staging the
+        // table in LDS instead measured 4 % slower)
+        const TriRec T = sc.tris[i];
+        tri_test<false, true>(&T, i, o.x, o.y, o.z, px, py, pz, shadow, h, n_tests, n_gate);
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_closest_hit(DeviceScene sc, const float4* __restrict__ origin,
@@ -141,10 +179,10 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
 // applied when the path ends, deepest vertex first, from a small per-lane stack of primitive
 // tags kept in LDS.
 
-// Register budget of the path kernel: 5 waves per SIMD (<= 96 VGPRs) measured fastest on the
-// fog-on Cornell workload (4: -8 %, 6: -2 %); the compiler's own choice (3-4 waves) is slower.
+// Register budget of the path kernel: 4 waves per SIMD (<= 128 VGPRs, no spills) measured fastest
+// on the fog-on Cornell workload (5 waves spill: -12 %; 3 waves: -14 %).
 #ifndef MIPT_WAVES_PER_EU
-#define MIPT_WAVES_PER_EU 5
+#define MIPT_WAVES_PER_EU 4
 #endif
 #define MIPT_PATHS_OCC __attribute__((amdgpu_waves_per_eu(MIPT_WAVES_PER_EU, MIPT_WAVES_PER_EU)))
 
@@ -159,7 +197,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   // Otherwise an item drawn from the global queue (see the loop head).
   const int lane = tid & 63;
   int x = 0, y = 0;
-  uint32_t s = 0, s_end = 0, pixel = 0;
+  uint32_t s = 0, s_end = 0, pixel = 0, pkey = 0;
   size_t list_i = 0;
   float* dst = nullptr;
   bool have = false;
@@ -169,11 +207,14 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       x = a.px[list_i]; y = a.py[list_i];
       s = a.samp[list_i]; s_end = s + 1;
       pixel = (uint32_t)(x * H + y);
+      pkey = pixel_key(P.seed, pixel);
       have = true;
     }
   }
-  uint32_t res_next = 0, res_end = 0;  // wave-uniform: the items of the last batch not handed out yet
-  bool drained = LIST;                 // wave-uniform: the queue has nothing left
+  // wave-uniform queue state: the items of the last batch not handed out yet, that batch's first
+  // id, tile and sample block, and whether the queue has run dry
+  uint32_t res_next = 0, res_end = 0, res_base = 0, res_sb = 0, res_tx = 0, res_ty = 0;
+  bool drained = LIST;
 
   float sum_r = 0.f, sum_g = 0.f, sum_b = 0.f;
   uint32_t st[ST_COUNT];
@@ -209,21 +250,24 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
             drained = true;
           } else {
             res_next = base;
-            res_end = base + 64u;  // n_items is a multiple of 64
+            res_end = base + 64u;  // n_items is a multiple of 64: a batch is one tile of one sample block
+            res_base = base;
+            res_sb = base / a.n_slots;
+            const uint32_t tile = (base - res_sb * a.n_slots) >> 6;
+            res_ty = tile / a.tiles_x;
+            res_tx = tile - res_ty * a.tiles_x;
           }
         }
         if (!drained) {
           const uint32_t avail = res_end - res_next;
           const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
           if (!have && rank < avail) {
-            const uint32_t item = res_next + rank;
-            const uint32_t sb = item / a.n_slots, slot = item - sb * a.n_slots;
-            const uint32_t tile = slot >> 6, l = slot & 63u;
-            const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-            x = (int)(tx * 8u + (l >> 3));
-            y = (int)(ty * 8u + (l & 7u));
+            const uint32_t l = res_next + rank - res_base, sb = res_sb;
+            x = (int)(res_tx * 8u + (l >> 3));
+            y = (int)(res_ty * 8u + (l & 7u));
             if (x < W && y < H) {
               pixel = (uint32_t)(x * H + y);
+              pkey = pixel_key(P.seed, pixel);
               s = a.sample_begin + sb * a.item_samples;
               const uint32_t last = a.sample_begin + a.sample_count;
               s_end = (s + a.item_samples < last) ? s + a.item_samples : last;
@@ -245,7 +289,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
     if (have) {
     if (fresh) {
       // main.cpp:124-133: two draws jitter the pixel, direction = Rx*Ry*d, not normalised
-      rng_begin<RNG_MODE>(rng, P.seed, pixel, s);
+      rng_begin<RNG_MODE>(rng, pkey, s);
       const float u1 = rng_next<RNG_MODE>(rng);
       const float u2 = rng_next<RNG_MODE>(rng);
       const float dvx = (float)((double)(x - W / 2) + (double)(u1 * 2.0f - 1.0f) * 0.1);
@@ -318,6 +362,10 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           }
         }
 
+        // Every branch below ends in normalize(new direction); the branches only prepare the
+        // vector and ONE normalisation runs for all lanes after they rejoin.
+        V4 nd = d;
+        bool renorm = false, offset_origin = false;
         const bool terminal = depth >= P.max_depth || rng_next<RNG_MODE>(rng) <= P.rr_prob;  // :80
         if (terminal) {
           // pathtracer.cpp:81-93 + directLight (light.cpp:13-31)
@@ -332,12 +380,17 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           const float r = sqrtf(dot4(v, v));
           const float den = (float)(((4.0 * 3.14159) * (double)r) * (double)r);  // light.cpp:22
           if (!medium) {
-            const V4 nn = normalize4(nrm);
+            // normalize(inter.normal) (light.cpp:20) is a per-triangle constant
+            const V4 nn = sphere_hit ? normalize4(nrm) : V4{sh.nnx, sh.nny, sh.nnz, sh.nnw};
             const float c = dot4(vecr, nn);
             const float m = (c < 0.f) ? 0.f : c;  // std::max(c, 0.f)
             Lr = (a.light_col[0] * m) / den;
-            Lg = (a.light_col[1] * m) / den;
-            Lb = (a.light_col[2] * m) / den;
+            if (a.light_gray) {
+              Lg = Lr; Lb = Lr;
+            } else {
+              Lg = (a.light_col[1] * m) / den;
+              Lb = (a.light_col[2] * m) / den;
+            }
             if (fog) {
               const float tr = fog_expf(-(P.fog_sigma_t * r));
               Lr = Lr * tr; Lg = Lg * tr; Lb = Lb * tr;
@@ -354,7 +407,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
             Lb = (((a.light_col[2] * phase) / den) * tr) * P.fog_albedo;
           }
           dfin = d;
-          d = normalize4(vecr);  // Ray ctor normalises again (ray.h:11-12)
+          nd = vecr; renorm = true;  // Ray ctor normalises again (ray.h:11-12)
           shadow_max = r;
           shadow = true;
         } else if (medium) {
@@ -376,15 +429,9 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           if (mat == MIPT_MAT_DIFFUSE) {
             // bounceDiffuse (pathtracer.cpp:5-19), orthonormalSystem / diffuseHemisphere (utils.cpp:10-22)
             if (STATS) st[ST_DIFFUSE]++;
-            V3 Nt;
-            if (fabsf(nrm.x) > fabsf(nrm.y)) {
-              const float len = sqrtf(nrm.x * nrm.x + nrm.z * nrm.z);
-              Nt = {nrm.z / len, 0.0f / len, -nrm.x / len};
-            } else {
-              const float len = sqrtf(nrm.y * nrm.y + nrm.z * nrm.z);
-              Nt = {0.0f / len, -nrm.z / len, nrm.y / len};
-            }
-            const V3 Nb = cross3({nrm.x, nrm.y, nrm.z}, Nt);
+            // orthonormalSystem(normal) is a per-triangle constant, stored with the triangle
+            V3 Nt = {sh.ntx, sh.nty, sh.ntz}, Nb = {sh.nbx, sh.nby, sh.nbz};
+            if (sphere_hit) orthonormal_system(nrm, Nt, Nb);
             // g++ evaluates the two argument draws right to left: first draw -> b, second -> a
             const float ub = rng_next<RNG_MODE>(rng);
             const float ua = rng_next<RNG_MODE>(rng);
@@ -398,8 +445,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
             rd.y = (sx * Nb.y + sy * nrm.y) + sz * Nt.y;
             rd.z = (sx * Nb.z + sy * nrm.z) + sz * Nt.z;
             rd.w = 1.0f;
-            d = normalize4(rd);
-            o = add4(o, scale4(d, 0.001f));
+            nd = rd; renorm = true; offset_origin = true;  // origin += dir * 0.001 after normalising
             tags[sp * BLOCK + tid] = (uint32_t)h.idx;
             if (sphere_hit) {
               float* q = sph_n + ((size_t)sp * BLOCK + tid) * 4;
@@ -410,40 +456,43 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
             // bounceMirror (pathtracer.cpp:21-27); weight 1, nothing to unwind
             if (STATS) st[ST_MIRROR]++;
             const float ct = dot4(nrm, d) * -1.0f;
-            d = normalize4(add4(d, scale4(nrm, ct * 2.0f)));
+            nd = add4(d, scale4(nrm, ct * 2.0f)); renorm = true;
             depth++;
           } else if (mat == MIPT_MAT_GLASS) {
             // bounceGlass (pathtracer.cpp:29-63)
             if (STATS) st[ST_GLASS]++;
-            float R0 = (P.ior_air - P.ior_glass) / (P.ior_air + P.ior_glass);
-            R0 = R0 * R0;
-            float eta = P.ior_glass;
+            const float R0 = a.glass_R0;
+            float eta = a.eta_enter;
             V4 n = nrm;
-            if (dot4(n, d) > 0.f) {
+            if (dot4(n, d) > 0.f) {  // inside the glass
               n = scale4(n, -1.0f);
-              eta = 1.0f / eta;
+              eta = a.eta_exit;
             }
-            eta = 1.0f / eta;
             const float c = dot4(n, d) * -1.0f;
             const float cost1 = (c < 0.f) ? 0.f : c;
             const float cost2 = 1.0f - (eta * eta) * (1.0f - cost1 * cost1);
             const float Rprob = R0 + (1.0f - R0) * pow5f(1.0f - cost1);
             if (cost2 > 0.f && rng_next<RNG_MODE>(rng) > Rprob) {
               const float kk = eta * cost1 - sqrtf(cost2);
-              d = normalize4(add4(scale4(d, eta), scale4(n, kk)));
+              nd = add4(scale4(d, eta), scale4(n, kk));
             } else {
-              d = normalize4(add4(d, scale4(n, cost1 * 2.0f)));
+              nd = add4(d, scale4(n, cost1 * 2.0f));
             }
+            renorm = true;
             tags[sp * BLOCK + tid] = TAG_GLASS;
             sp++; depth++;
           } else if (mat == MIPT_MAT_SPECULAR) {
             // bounceSpecular (pathtracer.cpp:65-70); weight 1
             const float k2 = dot4(d, nrm) * 2.f;
-            d = normalize4(sub4(d, scale4(nrm, k2)));
+            nd = sub4(d, scale4(nrm, k2)); renorm = true;
             depth++;
           } else {
             path_done = true;  // no branch of pathtracer.cpp:103-110 taken: colour stays 0
           }
+        }
+        if (renorm) {
+          d = normalize4(nd);
+          if (offset_origin) o = add4(o, scale4(d, 0.001f));  // pathtracer.cpp:14
         }
       }
     }
@@ -559,15 +608,18 @@ __global__ __launch_bounds__(BLOCK) void k_selfcheck_scan(DeviceScene sc, unsign
   }
   const float max_t = u01() * 2.5f;
   for (int mode = 0; mode < 2; ++mode) {
-    HitAcc f, e;
+    HitAcc f, e, g;
     f.set_lim(mode ? max_t : 3.402823466e+38f); f.idx = mode ? 0 : -1; f.by = f.bz = 0.f;
-    e = f;
+    e = f; g = f;
     uint32_t nt = 0, ng = 0;
-    scan_triangles<false, true>(sc, o, d, mode != 0, f, nt, ng);
-    scan_triangles<false, false>(sc, o, d, mode != 0, e, nt, ng);
-    const bool same = f.idx == e.idx && __float_as_uint(f.lim) == __float_as_uint(e.lim) &&
-                      __float_as_uint(f.by) == __float_as_uint(e.by) && __float_as_uint(f.bz) == __float_as_uint(e.bz);
-    if (!same) atomicAdd(out + 2 + mode, 1ull);
+    scan_triangles<false, SCAN_LITERAL>(sc, o, d, mode != 0, e, nt, ng);
+    scan_triangles<false, SCAN_FAST>(sc, o, d, mode != 0, f, nt, ng);
+    scan_triangles<false, SCAN_TWO_PHASE>(sc, o, d, mode != 0, g, nt, ng);
+    auto same = [](const HitAcc& a, const HitAcc& b) {
+      return a.idx == b.idx && __float_as_uint(a.lim) == __float_as_uint(b.lim) &&
+             __float_as_uint(a.by) == __float_as_uint(b.by) && __float_as_uint(a.bz) == __float_as_uint(b.bz);
+    };
+    if (!same(f, e) || !same(g, e)) atomicAdd(out + 2 + mode, 1ull);
   }
 }
 
