@@ -58,7 +58,8 @@ class MiptStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("gate_passes", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("fog_events", C.c_uint64), ("diffuse_bounces", C.c_uint64),
-                ("mirror_bounces", C.c_uint64), ("glass_bounces", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("mirror_bounces", C.c_uint64), ("glass_bounces", C.c_uint64), ("bvh_redo", C.c_uint64),
+                ("bvh_overflow", C.c_uint64), ("kernel_ms", C.c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -81,7 +82,7 @@ EXPORTS = [
     "mipt_scene_destroy", "mipt_closest_hit", "mipt_any_hit", "mipt_render_accumulate",
     "mipt_resolve_argb", "mipt_trace_paths", "mipt_closest_hit_dev", "mipt_any_hit_dev",
     "mipt_render_accumulate_dev", "mipt_resolve_argb_dev", "mipt_get_stats", "mipt_path_key",
-    "mipt_load_test_model", "mipt_default_camera", "mipt_default_light", "mipt_debug_selfcheck",
+    "mipt_load_test_model", "mipt_default_camera", "mipt_default_light", "mipt_debug_selfcheck", "mipt_scene_has_bvh",
 ]
 
 
@@ -129,7 +130,8 @@ def load_library(path=None):
     lib.mipt_get_stats.argtypes = [vp, P(MiptStats)]
     lib.mipt_path_key.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     lib.mipt_path_key.restype = C.c_uint32
-    lib.mipt_debug_selfcheck.argtypes = [vp, C.c_uint64, C.c_uint32, P(C.c_uint64 * 4)]
+    lib.mipt_debug_selfcheck.argtypes = [vp, C.c_uint64, C.c_uint32, P(C.c_uint64 * 8)]
+    lib.mipt_scene_has_bvh.argtypes = [vp, P(C.c_uint64), P(C.c_double)]
     lib.mipt_load_test_model.argtypes = [C.c_int, vp, C.c_size_t]
     lib.mipt_default_camera.argtypes = [P(MiptCamera), C.c_int]
     lib.mipt_default_camera.restype = None

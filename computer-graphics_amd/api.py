@@ -159,9 +159,16 @@ class Scene:
         """Device-side comparison of the fast arithmetic with the literal reference arithmetic:
         returns (reciprocal mismatches over all 2^32 floats, worst hardware-reciprocal error in ulp,
         closest-hit mismatches, any-hit mismatches) for n_rays generated rays."""
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 8)()
         _check(self._lib.mipt_debug_selfcheck(self._h, n_rays, seed, C.byref(out)))
+        self.last_selfcheck_bvh = (int(out[4]), int(out[5]))  # (exhaustive re-runs, overflows)
         return int(out[0]), out[1] / 1024.0, int(out[2]), int(out[3])
+
+    def bvh_info(self):
+        """(has an LBVH, node count, build milliseconds)"""
+        n, ms = C.c_uint64(), C.c_double()
+        has = self._lib.mipt_scene_has_bvh(self._h, C.byref(n), C.byref(ms))
+        return bool(has), int(n.value), float(ms.value)
 
     def stats(self):
         s = abi.MiptStats()

@@ -10,6 +10,8 @@
 #include <new>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>
+
 #include "mipt_kernels.hpp"
 
 using namespace mipt;
@@ -52,6 +54,8 @@ struct MiptScene {
   uint32_t* d_queue = nullptr;
   float* d_partial = nullptr;
   size_t partial_bytes = 0;
+  BvhNode* d_bvh = nullptr;
+  double bvh_build_ms = 0.0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   bool stats_valid = false;
@@ -67,12 +71,82 @@ static void scene_free(MiptScene* s) {
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_queue) (void)hipFree(s->d_queue);
   if (s->d_partial) (void)hipFree(s->d_partial);
+  if (s->d_bvh) (void)hipFree(s->d_bvh);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
 }
 
 extern "C" void mipt_scene_destroy(MiptScene* s) { scene_free(s); }
+
+// RAII device buffer for temporaries and the host-pointer entry points
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  template <typename T> T* as() { return static_cast<T*>(p); }
+};
+
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+// LBVH over s->d_tris (n >= 2): bounds -> Morton keys -> radix sort -> topology -> refit waves.
+// Everything runs on the null stream of the scene's device; the tree is final on return.
+static int build_bvh(MiptScene* s, int n) {
+  DevBuf box, cen, scene, keys, ids, keys2, ids2, node_box, ready, done, tmp;
+  HIP_TRY(box.alloc((size_t)n * sizeof(Aabb)));
+  HIP_TRY(cen.alloc((size_t)n * 12));
+  HIP_TRY(scene.alloc(6 * 4));
+  HIP_TRY(keys.alloc((size_t)n * 8)); HIP_TRY(keys2.alloc((size_t)n * 8));
+  HIP_TRY(ids.alloc((size_t)n * 4)); HIP_TRY(ids2.alloc((size_t)n * 4));
+  HIP_TRY(node_box.alloc((size_t)n * sizeof(Aabb)));
+  HIP_TRY(ready.alloc((size_t)n * 2));
+  HIP_TRY(done.alloc(4));
+  HIP_TRY(hipMalloc(&s->d_bvh, (size_t)(n - 1) * sizeof(BvhNode)));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+  HIP_TRY(hipMemcpy(scene.p, init, sizeof init, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_bvh_bounds, dim3(grid_for(n)), dim3(BLOCK), 0, nullptr, s->d_tris, n, box.as<Aabb>(),
+                     cen.as<float>(), scene.as<uint32_t>());
+  hipLaunchKernelGGL(k_bvh_morton, dim3(grid_for(n)), dim3(BLOCK), 0, nullptr, cen.as<float>(), n,
+                     scene.as<uint32_t>(), keys.as<unsigned long long>(), ids.as<int>());
+  HIP_TRY(hipGetLastError());
+  size_t tmp_bytes = 0;
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<unsigned long long>(), keys2.as<unsigned long long>(),
+                                    ids.as<int>(), ids2.as<int>(), (size_t)n, 0, 63, nullptr));
+  HIP_TRY(tmp.alloc(tmp_bytes));
+  HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<unsigned long long>(), keys2.as<unsigned long long>(),
+                                    ids.as<int>(), ids2.as<int>(), (size_t)n, 0, 63, nullptr));
+  hipLaunchKernelGGL(k_bvh_topology, dim3(grid_for(n - 1)), dim3(BLOCK), 0, nullptr, keys2.as<unsigned long long>(),
+                     ids2.as<int>(), n, s->d_bvh);
+  HIP_TRY(hipGetLastError());
+  // refit: ready flags ping-pong between the two halves of `ready`; the count of finished nodes
+  // is read back once per wave (a tree over sorted Morton keys is ~log2(n) + a few levels deep)
+  HIP_TRY(hipMemset(ready.p, 0, (size_t)n * 2));
+  HIP_TRY(hipMemset(done.p, 0, 4));
+  unsigned char* r0 = ready.as<unsigned char>();
+  unsigned char* r1 = r0 + n;
+  int n_done = 0, prev = -1, waves = 0;
+  while (n_done < n - 1) {
+    if (n_done == prev || ++waves > 4096)
+      return fail(MIPT_E_HIP, "LBVH refit stalled at %d of %d nodes after %d waves", n_done, n - 1, waves);
+    prev = n_done;
+    hipLaunchKernelGGL(k_bvh_refit, dim3(grid_for(n - 1)), dim3(BLOCK), 0, nullptr, s->d_bvh, n, box.as<Aabb>(),
+                       node_box.as<Aabb>(), r1, r0, done.as<int>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(&n_done, done.p, 4, hipMemcpyDeviceToHost));
+    std::swap(r0, r1);
+  }
+  HIP_TRY(hipEventRecord(e1, nullptr));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  s->bvh_build_ms = ms;
+  s->d.bvh = s->d_bvh;
+  return MIPT_OK;
+}
 
 static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
                              size_t n_spheres, int device, MiptScene* s) {
@@ -81,6 +155,7 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
   std::vector<TriRec> tr(n_tris ? n_tris : 1);
   std::vector<ShadeRec> sh(n_tris + n_spheres ? n_tris + n_spheres : 1);
   std::vector<SphereRec> sp(n_spheres ? n_spheres : 1);
+  float scale = 0.f;
   for (size_t i = 0; i < n_tris; ++i) {
     const MiptTriangle& t = tris[i];
     TriRec& r = tr[i];
@@ -89,6 +164,10 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
     // intersections.cpp:17-18; plain float subtraction, same on host and device
     volatile float e1x = t.v1[0] - t.v0[0], e1y = t.v1[1] - t.v0[1], e1z = t.v1[2] - t.v0[2];
     volatile float e2x = t.v2[0] - t.v0[0], e2y = t.v2[1] - t.v0[1], e2z = t.v2[2] - t.v0[2];
+    for (int k = 0; k < 3; ++k) {
+      const float m = std::fmax(std::fabs(t.v0[k]), std::fmax(std::fabs(t.v1[k]), std::fabs(t.v2[k])));
+      if (m > scale && m <= 1.0995116e12f) scale = m;
+    }
     r.e1x = e1x; r.e1y = e1y; r.e1z = e1z;
     r.e2x = e2x; r.e2y = e2y; r.e2z = e2z;
     // cofactors; each product is stored before the subtraction so that no FMA can form
@@ -148,6 +227,9 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
   s->d.spheres = s->d_spheres;
   s->d.n_tris = (int)n_tris;
   s->d.n_spheres = (int)n_spheres;
+  s->d.scale = scale;
+  const char* no_bvh = getenv("MIPT_NO_BVH");  // developer switch: always scan linearly
+  if (n_tris >= MIPT_BVH_MIN_TRIS && !(no_bvh && no_bvh[0] == '1')) return build_bvh(s, (int)n_tris);
   return MIPT_OK;
 }
 
@@ -181,7 +263,14 @@ extern "C" int mipt_scene_create(const MiptTriangle* tris, size_t n_tris, const 
 // ---------------------------------------------------------------------------------------
 // batch queries
 
-static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+extern "C" int mipt_scene_has_bvh(MiptScene* s, uint64_t* n_nodes, double* build_ms) {
+  if (n_nodes) *n_nodes = 0;
+  if (build_ms) *build_ms = 0.0;
+  if (!s || !s->d.bvh) return 0;
+  if (n_nodes) *n_nodes = (uint64_t)(s->d.n_tris - 1);
+  if (build_ms) *build_ms = s->bvh_build_ms;
+  return 1;
+}
 
 extern "C" int mipt_closest_hit_dev(MiptScene* s, const float* d_origin4, const float* d_dir4, size_t n_rays,
                                     int32_t* d_tri_idx, float* d_t, float* d_position4, void* stream) {
@@ -190,9 +279,14 @@ extern "C" int mipt_closest_hit_dev(MiptScene* s, const float* d_origin4, const 
   if (!d_origin4 || !d_dir4 || !d_tri_idx || !d_t) return fail(MIPT_E_INVALID, "mipt_closest_hit: null buffer");
   if (n_rays > ((size_t)1 << 31) * BLOCK) return fail(MIPT_E_INVALID, "mipt_closest_hit: too many rays");
   HIP_TRY(hipSetDevice(s->device));
-  hipLaunchKernelGGL(k_closest_hit, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
-                     (const float4*)d_origin4, (const float4*)d_dir4, n_rays, d_tri_idx, d_t,
-                     (float4*)d_position4);
+  if (s->d.bvh)
+    hipLaunchKernelGGL(k_closest_hit<true>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
+                       (const float4*)d_origin4, (const float4*)d_dir4, n_rays, d_tri_idx, d_t,
+                       (float4*)d_position4);
+  else
+    hipLaunchKernelGGL(k_closest_hit<false>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
+                       (const float4*)d_origin4, (const float4*)d_dir4, n_rays, d_tri_idx, d_t,
+                       (float4*)d_position4);
   HIP_TRY(hipGetLastError());
   return MIPT_OK;
 }
@@ -204,19 +298,15 @@ extern "C" int mipt_any_hit_dev(MiptScene* s, const float* d_origin4, const floa
   if (!d_origin4 || !d_dir4 || !d_max_t || !d_occluded) return fail(MIPT_E_INVALID, "mipt_any_hit: null buffer");
   if (n_rays > ((size_t)1 << 31) * BLOCK) return fail(MIPT_E_INVALID, "mipt_any_hit: too many rays");
   HIP_TRY(hipSetDevice(s->device));
-  hipLaunchKernelGGL(k_any_hit, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
-                     (const float4*)d_origin4, (const float4*)d_dir4, d_max_t, n_rays, d_occluded);
+  if (s->d.bvh)
+    hipLaunchKernelGGL(k_any_hit<true>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
+                       (const float4*)d_origin4, (const float4*)d_dir4, d_max_t, n_rays, d_occluded);
+  else
+    hipLaunchKernelGGL(k_any_hit<false>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
+                       (const float4*)d_origin4, (const float4*)d_dir4, d_max_t, n_rays, d_occluded);
   HIP_TRY(hipGetLastError());
   return MIPT_OK;
 }
-
-// RAII device buffer for the host-pointer entry points
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-  template <typename T> T* as() { return static_cast<T*>(p); }
-};
 
 extern "C" int mipt_closest_hit(MiptScene* s, const float* origin4, const float* dir4, size_t n_rays,
                                 int32_t* tri_idx, float* t, float* position4) {
@@ -321,17 +411,23 @@ static size_t stack_bytes(const MiptScene* s, const MiptParams* p) {
   return per_level * (size_t)p->max_depth;
 }
 
-template <bool LIST>
-static void launch_paths(const PathArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+template <bool LIST, bool BVH>
+static void launch_paths_kind(const PathArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   const bool stats = (a.p.flags & MIPT_FLAG_STATS) != 0;
   const bool counter = a.p.rng_mode == MIPT_RNG_COUNTER;
   if (counter) {
-    if (stats) hipLaunchKernelGGL((k_paths<MIPT_RNG_COUNTER, true, LIST>), grid, dim3(BLOCK), lds, st, a);
-    else hipLaunchKernelGGL((k_paths<MIPT_RNG_COUNTER, false, LIST>), grid, dim3(BLOCK), lds, st, a);
+    if (stats) hipLaunchKernelGGL((k_paths<MIPT_RNG_COUNTER, true, LIST, BVH>), grid, dim3(BLOCK), lds, st, a);
+    else hipLaunchKernelGGL((k_paths<MIPT_RNG_COUNTER, false, LIST, BVH>), grid, dim3(BLOCK), lds, st, a);
   } else {
-    if (stats) hipLaunchKernelGGL((k_paths<MIPT_RNG_MINSTD_PATH, true, LIST>), grid, dim3(BLOCK), lds, st, a);
-    else hipLaunchKernelGGL((k_paths<MIPT_RNG_MINSTD_PATH, false, LIST>), grid, dim3(BLOCK), lds, st, a);
+    if (stats) hipLaunchKernelGGL((k_paths<MIPT_RNG_MINSTD_PATH, true, LIST, BVH>), grid, dim3(BLOCK), lds, st, a);
+    else hipLaunchKernelGGL((k_paths<MIPT_RNG_MINSTD_PATH, false, LIST, BVH>), grid, dim3(BLOCK), lds, st, a);
   }
+}
+
+template <bool LIST>
+static void launch_paths(const PathArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  if (a.sc.bvh) launch_paths_kind<LIST, true>(a, grid, lds, st);
+  else launch_paths_kind<LIST, false>(a, grid, lds, st);
 }
 
 extern "C" int mipt_render_accumulate_dev(MiptScene* s, const MiptCamera* cam, const MiptLight* light,
@@ -474,6 +570,7 @@ extern "C" int mipt_get_stats(MiptScene* s, MiptStats* out) {
     out->tri_tests = h[ST_TESTS]; out->gate_passes = h[ST_GATE];
     out->sphere_tests = h[ST_SPHERE]; out->fog_events = h[ST_FOG];
     out->diffuse_bounces = h[ST_DIFFUSE]; out->mirror_bounces = h[ST_MIRROR]; out->glass_bounces = h[ST_GLASS];
+    out->bvh_redo = h[ST_BVH_REDO]; out->bvh_overflow = h[ST_BVH_OVERFLOW];
   }
   return MIPT_OK;
 }
@@ -513,24 +610,29 @@ extern "C" int mipt_resolve_argb(MiptScene* s, const float* accum_rgb, int width
   return MIPT_OK;
 }
 
-extern "C" int mipt_debug_selfcheck(MiptScene* s, uint64_t n_rays, uint32_t seed, uint64_t out[4]) {
+extern "C" int mipt_debug_selfcheck(MiptScene* s, uint64_t n_rays, uint32_t seed, uint64_t out[8]) {
   if (!s || !out) return fail(MIPT_E_INVALID, "mipt_debug_selfcheck: null argument");
   if (n_rays > ((uint64_t)1 << 36)) return fail(MIPT_E_INVALID, "mipt_debug_selfcheck: at most 2^36 rays per call");
   HIP_TRY(hipSetDevice(s->device));
   DevBuf d;
-  HIP_TRY(d.alloc(4 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(d.p, 0, 4 * sizeof(unsigned long long)));
+  HIP_TRY(d.alloc(8 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(d.p, 0, 8 * sizeof(unsigned long long)));
   hipLaunchKernelGGL(k_selfcheck_rcp, dim3(4096 / BLOCK), dim3(BLOCK), 0, nullptr, d.as<unsigned long long>());
   HIP_TRY(hipGetLastError());
   if (n_rays) {
-    hipLaunchKernelGGL(k_selfcheck_scan, dim3((unsigned)((n_rays + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, nullptr, s->d,
-                       (unsigned long long)n_rays, seed, d.as<unsigned long long>());
+    const dim3 grid((unsigned)((n_rays + BLOCK - 1) / BLOCK));
+    if (s->d.bvh)
+      hipLaunchKernelGGL(k_selfcheck_scan<true>, grid, dim3(BLOCK), 0, nullptr, s->d, (unsigned long long)n_rays,
+                         seed, d.as<unsigned long long>());
+    else
+      hipLaunchKernelGGL(k_selfcheck_scan<false>, grid, dim3(BLOCK), 0, nullptr, s->d, (unsigned long long)n_rays,
+                         seed, d.as<unsigned long long>());
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipDeviceSynchronize());
-  unsigned long long h[4];
+  unsigned long long h[8];
   HIP_TRY(hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost));
-  for (int i = 0; i < 4; ++i) out[i] = h[i];
+  for (int i = 0; i < 8; ++i) out[i] = h[i];
   return MIPT_OK;
 }
 

@@ -1,0 +1,416 @@
+// mipt_bvh.hpp -- GPU-built LBVH and its traversal, for scenes too large for the linear scan.
+//
+// The reference has no acceleration structure (AABB.h is included by main.cpp:40 but never
+// used); its closestIntersection is a linear scan whose result depends on the ORDER of the
+// triangles only through near-ties. The traversal here therefore does not reimplement the
+// reference's rule in tree order; it uses the tree to find the few triangles whose reference
+// test can succeed near the front of the ray, evaluates those with the reference's own
+// arithmetic, and replays the reference's sequential rule over them in index order:
+//
+//   build     triangle bounds -> 63-bit Morton keys of the centroids -> radix sort (rocPRIM) ->
+//             Karras' parallel radix-tree construction -> bottom-up refit, one launch per level
+//             wave (kernel boundaries order the writes; no inter-workgroup flags).
+//   node      64 bytes: the two children's boxes and two child references (>= 0 inner node,
+//             < 0 leaf holding triangle -1 - ref). One node = one 64-byte line.
+//   leaf box  the triangle's bounds grown by 3 % of its extent: the candidate filter
+//             (tri_candidate) admits hits up to 2 % of an edge outside the triangle.
+//   closest   stack traversal, near child first; at a leaf the candidate filter, then the
+//             reference's determinant ratio t, inverse-path distance z = |x.x| and barycentrics.
+//             A triangle the reference could accept (t >= 0, barycentrics valid) is kept in a
+//             small list sorted by index; boxes and hits beyond zmin (1 + 2^-9) + 4 delta are
+//             dropped, zmin = smallest z so far and delta an absolute slack for the rounding noise
+//             of hits at t ~ 0. At the end the reference's rule `t <= min -> min = z` runs over the
+//             list in index order. While every hit met has |t - z| <= 2^-12 z + delta this equals
+//             the rule run over all triangles: a dropped hit lies behind every kept one by more
+//             than the noise, so it is either rejected by the reference too, or accepted before the
+//             closest hit and then overridden by it. A hit whose t and z disagree more (ill-
+//             conditioned for this ray), or a full list, sends the ray through the exhaustive
+//             traversal: no pruning, one pass over the ray's boxes per triangle the reference
+//             accepts.
+//   any-hit   existsIntersection is an OR over the triangles (its `break` only shortens the
+//             loop), so the traversal stops at the first leaf whose reference test accepts.
+//
+// Equality with the linear scan is exact except in one corner: a triangle whose padded box the
+// ray never enters, or enters beyond the pruning distance, but whose reference test is so
+// ill-conditioned for this ray (ray within ~0.01 degrees of the triangle's plane AND nearly in
+// that plane) that its rounding noise alone produces an accepted hit in front of the true one.
+#pragma once
+
+#include "mipt_device.hpp"
+
+namespace mipt {
+
+struct __attribute__((aligned(64))) BvhNode {
+  float lmin[3], lmax[3], rmin[3], rmax[3];
+  int left, right;
+  int pad0, pad1;
+};
+
+struct Aabb { float lo[3], hi[3]; };
+
+// ---------------------------------------------------------------------------------------
+// build kernels
+
+__device__ __forceinline__ uint32_t float_flip(float f) {  // order-preserving float -> uint
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float float_unflip(uint32_t u) {
+  const uint32_t v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  f = __uint_as_float(v);
+#else
+  memcpy(&f, &v, 4);
+#endif
+  return f;
+}
+
+// per triangle: padded bounds; scene bounds of the centroids by atomics on flipped floats
+__global__ __launch_bounds__(BLOCK) void k_bvh_bounds(const TriRec* __restrict__ tris, int n, Aabb* __restrict__ box,
+                                                      float* __restrict__ centroid, uint32_t* __restrict__ scene) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const TriRec T = tris[i];
+  const float v0[3] = {T.v0x, T.v0y, T.v0z};
+  const float e1[3] = {T.e1x, T.e1y, T.e1z}, e2[3] = {T.e2x, T.e2y, T.e2z};
+  Aabb b;
+  float ext = 0.f, mag = 0.f;
+  for (int k = 0; k < 3; ++k) {
+    const float a = v0[k], c = v0[k] + e1[k], d = v0[k] + e2[k];
+    b.lo[k] = fminf(a, fminf(c, d));
+    b.hi[k] = fmaxf(a, fmaxf(c, d));
+    ext = fmaxf(ext, b.hi[k] - b.lo[k]);
+    mag = fmaxf(mag, fmaxf(fabsf(b.lo[k]), fabsf(b.hi[k])));
+  }
+  const float pad = 0.03f * ext + 1e-5f * mag + 1e-30f;
+  for (int k = 0; k < 3; ++k) {
+    centroid[3 * i + k] = 0.5f * (b.lo[k] + b.hi[k]);
+    atomicMin(scene + k, float_flip(centroid[3 * i + k]));
+    atomicMax(scene + 3 + k, float_flip(centroid[3 * i + k]));
+    b.lo[k] -= pad;
+    b.hi[k] += pad;
+  }
+  box[i] = b;
+}
+
+__device__ __forceinline__ unsigned long long spread21(unsigned long long v) {  // 21 bits -> every third bit
+  v &= 0x1FFFFFull;
+  v = (v | v << 32) & 0x1F00000000FFFFull;
+  v = (v | v << 16) & 0x1F0000FF0000FFull;
+  v = (v | v << 8) & 0x100F00F00F00F00Full;
+  v = (v | v << 4) & 0x10C30C30C30C30C3ull;
+  v = (v | v << 2) & 0x1249249249249249ull;
+  return v;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bvh_morton(const float* __restrict__ centroid, int n,
+                                                      const uint32_t* __restrict__ scene,
+                                                      unsigned long long* __restrict__ keys, int* __restrict__ ids) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long code = 0;
+  for (int k = 0; k < 3; ++k) {
+    const float lo = float_unflip(scene[k]), hi = float_unflip(scene[3 + k]);
+    const float w = hi - lo;
+    float u = (w > 0.f) ? (centroid[3 * i + k] - lo) / w : 0.f;
+    u = fminf(fmaxf(u, 0.f), 1.f);
+    const unsigned long long q = (unsigned long long)fminf(u * 2097152.0f, 2097151.0f);
+    code |= spread21(q) << k;
+  }
+  keys[i] = code;
+  ids[i] = i;
+}
+
+// common-prefix length of sorted keys i and j; equal keys are told apart by their position
+__device__ __forceinline__ int bvh_delta(const unsigned long long* keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const unsigned long long a = keys[i], b = keys[j];
+  if (a == b) return 64 + __clz((unsigned)(i ^ j));
+  return __clzll((long long)(a ^ b));
+}
+
+// Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees"
+__global__ __launch_bounds__(BLOCK) void k_bvh_topology(const unsigned long long* __restrict__ keys,
+                                                        const int* __restrict__ ids, int n,
+                                                        BvhNode* __restrict__ nodes) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = (bvh_delta(keys, n, i, i + 1) - bvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = bvh_delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (bvh_delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (bvh_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = bvh_delta(keys, n, i, j);
+  int s = 0;
+  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+    if (bvh_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    if (t <= 1) break;
+  }
+  const int gamma = i + s * d + (d < 0 ? d : 0);
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  // a child that covers a single sorted key is a leaf holding that key's triangle
+  nodes[i].left = (lo == gamma) ? -1 - ids[gamma] : gamma;
+  nodes[i].right = (hi == gamma + 1) ? -1 - ids[gamma + 1] : gamma + 1;
+}
+
+// one refit wave: every inner node whose children both have boxes computes its own.
+// node_box[0..n-2] inner, ready[] likewise; leaves take their box from tri_box.
+__global__ __launch_bounds__(BLOCK) void k_bvh_refit(BvhNode* __restrict__ nodes, int n, const Aabb* __restrict__ tri_box,
+                                                     Aabb* __restrict__ node_box, unsigned char* __restrict__ ready,
+                                                     const unsigned char* __restrict__ ready_prev,
+                                                     int* __restrict__ n_done) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n - 1) return;
+  if (ready_prev[i]) { ready[i] = 1; return; }
+  const int l = nodes[i].left, r = nodes[i].right;
+  const bool lok = l < 0 || ready_prev[l], rok = r < 0 || ready_prev[r];
+  if (!(lok && rok)) { ready[i] = 0; return; }
+  const Aabb a = l < 0 ? tri_box[-1 - l] : node_box[l];
+  const Aabb b = r < 0 ? tri_box[-1 - r] : node_box[r];
+  Aabb u;
+  for (int k = 0; k < 3; ++k) {
+    nodes[i].lmin[k] = a.lo[k]; nodes[i].lmax[k] = a.hi[k];
+    nodes[i].rmin[k] = b.lo[k]; nodes[i].rmax[k] = b.hi[k];
+    u.lo[k] = fminf(a.lo[k], b.lo[k]);
+    u.hi[k] = fmaxf(a.hi[k], b.hi[k]);
+  }
+  node_box[i] = u;
+  ready[i] = 1;
+  atomicAdd(n_done, 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// traversal
+
+// The reference's quantities for one triangle, without the sequential gate: t = detM / detA
+// (intersections.cpp:23), x = inverse(A) * b (:26). Same operations as tri_test.
+template <typename TP>
+__device__ __forceinline__ void tri_eval(TP T, float ox, float oy, float oz, float px, float py, float pz,
+                                         float& t, float& x0, float& x1, float& x2) {
+  const float bx = ox - T->v0x, by = oy - T->v0y, bz = oz - T->v0z;
+  const float e1x = T->e1x, e1y = T->e1y, e1z = T->e1z;
+  const float e2x = T->e2x, e2y = T->e2y, e2z = T->e2z;
+  const float c0 = T->c0;
+  const float m1 = by * e2z - e2y * bz;
+  const float m2 = by * e1z - e1y * bz;
+  const float detM = ((bx * c0) - (e1x * m1)) + (e2x * m2);
+  const float k1 = py * e2z - e2y * pz;
+  const float k2 = py * e1z - e1y * pz;
+  const float detA = ((px * c0) - (e1x * k1)) + (e2x * k2);
+  t = detM / detA;
+  const float ood = rcp_exact(detA, __builtin_amdgcn_rcpf(detA));
+  const float i00 = c0 * ood;
+  const float i10 = -(T->c1) * ood;
+  const float i20 = T->c2 * ood;
+  const float i01 = -k1 * ood;
+  const float i11 = (px * e2z - e2x * pz) * ood;
+  const float i21 = -(px * e2y - e2x * py) * ood;
+  const float i02 = k2 * ood;
+  const float i12 = -(px * e1z - e1x * pz) * ood;
+  const float i22 = (px * e1y - e1x * py) * ood;
+  x0 = (i00 * bx + i10 * by) + i20 * bz;
+  x1 = (i01 * bx + i11 * by) + i21 * bz;
+  x2 = (i02 * bx + i12 * by) + i22 * bz;
+}
+
+struct BvhHit { int idx; float t, z, by, bz; };
+
+// A tree over sorted 63-bit keys, equal keys split by their 32-bit position, is at most 95 levels
+// deep, and the traversal pushes at most one entry per level: the stack cannot overflow.
+constexpr int BVH_STACK = 96;
+constexpr int BVH_LIST = 8;               // hits kept by the pruned traversal
+constexpr float BVH_BAND = 1.001953125f;  // 1 + 2^-9
+
+__device__ __forceinline__ bool slab(const float lo[3], const float hi[3], V3 o, V3 inv, float bound, float& tnear) {
+  const float ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
+  const float ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
+  const float az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+  // fminf / fmaxf drop a NaN operand (0 * inf when the origin lies on a slab plane of a ray
+  // parallel to it), which keeps the test conservative
+  const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+  const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+  tnear = t0;
+  return t0 <= t1 * 1.0000004f + 1e-30f && t1 >= 0.f && t0 <= bound;
+}
+
+struct BvhRay {
+  V4 o, d;
+  V3 oo, inv;
+  float px, py, pz, Dm, delta;
+};
+
+__device__ __forceinline__ BvhRay bvh_ray(const DeviceScene& sc, V4 o, V4 d) {
+  BvhRay r;
+  r.o = o; r.d = d;
+  r.px = -d.x; r.py = -d.y; r.pz = -d.z;
+  const float Dabs = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+  const float Om = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+  const bool sane = Dabs >= 9.094947e-13f && Dabs <= 1.0995116e12f && Om <= 1.0995116e12f;
+  r.Dm = sane ? Dabs : __builtin_inff();
+  // absolute slack on ray parameters: the determinant ratio of a triangle the origin lies on is
+  // rounding noise of about 2^-23 (|o| + |v|) / (|d| cos(angle to the normal))
+  r.delta = sane ? 0.0001220703125f * (sc.scale + Om) / Dabs : 0.f;  // 2^-13
+  r.oo = {o.x, o.y, o.z};
+  r.inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+  return r;
+}
+
+// could the reference accept this triangle at all? intersections.cpp:25 with min = FLT_MAX, :27
+__device__ __forceinline__ bool bvh_leaf(const DeviceScene& sc, const BvhRay& r, int i, float& t, float& z,
+                                         float& x1, float& x2) {
+  const TriRec T = sc.tris[i];
+  if (!tri_candidate(&T, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.Dm)) return false;
+  float x0;
+  tri_eval(&T, r.o.x, r.o.y, r.o.z, r.px, r.py, r.pz, t, x0, x1, x2);
+  z = fabsf(x0);
+  return t >= 0.0f && t <= 3.402823466e+38f && x1 >= 0.0f && x2 >= 0.0f &&
+         (x1 + x2) <= __uint_as_float(0x3F8020C4u);
+}
+
+// Closest hit through the tree with distance pruning. Returns false if the ray has to be redone
+// by bvh_closest_exhaustive (a hit whose t and z disagree, or more near-ties than the list holds).
+__device__ __forceinline__ bool bvh_closest(const DeviceScene& sc, const BvhNode* __restrict__ nodes,
+                                            const BvhRay& r, HitAcc& h, uint32_t& overflow) {
+  BvhHit list[BVH_LIST];
+  int n_list = 0;
+  float zmin = 3.402823466e+38f, bound = 3.402823466e+38f;
+  int stack[BVH_STACK];
+  int sp = 0;
+  int cur = sc.n_tris > 1 ? 0 : -1;  // a single triangle is its own tree
+  for (;;) {
+    if (cur < 0) {
+      const int i = -1 - cur;
+      float t, z, x1, x2;
+      if (bvh_leaf(sc, r, i, t, z, x1, x2)) {
+        if (!(fabsf(t - z) <= 0.000244140625f * z + r.delta)) return false;  // 2^-12
+        if (z < zmin) {
+          zmin = z;
+          bound = zmin * BVH_BAND + 4.0f * r.delta;
+          int w = 0;  // drop hits that fell out of the band
+          for (int k = 0; k < n_list; ++k)
+            if (list[k].t <= bound) list[w++] = list[k];
+          n_list = w;
+        }
+        if (t <= bound) {
+          if (n_list == BVH_LIST) return false;
+          int k = n_list++;
+          while (k > 0 && list[k - 1].idx > i) { list[k] = list[k - 1]; --k; }  // keep index order
+          list[k] = {i, t, z, x1, x2};
+        }
+      }
+      if (sp == 0) break;
+      cur = stack[--sp];
+      continue;
+    }
+    const BvhNode N = nodes[cur];
+    float tl, tr;
+    const bool hl = slab(N.lmin, N.lmax, r.oo, r.inv, bound, tl);
+    const bool hr = slab(N.rmin, N.rmax, r.oo, r.inv, bound, tr);
+    if (hl && hr) {
+      const bool left_first = tl <= tr;
+      if (sp >= BVH_STACK) { overflow++; return false; }
+      stack[sp++] = left_first ? N.right : N.left;
+      cur = left_first ? N.left : N.right;
+    } else if (hl || hr) {
+      cur = hl ? N.left : N.right;
+    } else {
+      if (sp == 0) break;
+      cur = stack[--sp];
+    }
+  }
+  // the reference's sequential rule over the surviving hits, in index order (:25, :28)
+  for (int k = 0; k < n_list; ++k) {
+    if (list[k].t <= h.lim) {
+      h.set_lim(list[k].z);
+      h.idx = list[k].idx;
+      h.by = list[k].by;
+      h.bz = list[k].bz;
+    }
+  }
+  return true;
+}
+
+// The same without any assumption about distances: the reference's scan accepts, after triangle
+// `after`, the lowest-numbered triangle that passes its test against the current limit; each
+// pass walks every box the ray touches to find that triangle, until a pass finds none.
+__device__ __forceinline__ void bvh_closest_exhaustive(const DeviceScene& sc, const BvhNode* __restrict__ nodes,
+                                                       const BvhRay& r, HitAcc& h, uint32_t& overflow) {
+  int after = -1;
+  for (;;) {
+    int best = 0x7FFFFFFF;
+    float bz = 0.f, b1 = 0.f, b2 = 0.f;
+    int stack[BVH_STACK];
+    int sp = 0;
+    int cur = sc.n_tris > 1 ? 0 : -1;
+    for (;;) {
+      if (cur < 0) {
+        const int i = -1 - cur;
+        float t, z, x1, x2;
+        if (i > after && i < best && bvh_leaf(sc, r, i, t, z, x1, x2) && t <= h.lim) {
+          best = i; bz = z; b1 = x1; b2 = x2;
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+        continue;
+      }
+      const BvhNode N = nodes[cur];
+      float tl, tr;
+      const bool hl = slab(N.lmin, N.lmax, r.oo, r.inv, 3.402823466e+38f, tl);
+      const bool hr = slab(N.rmin, N.rmax, r.oo, r.inv, 3.402823466e+38f, tr);
+      if (hl && hr) {
+        if (sp >= BVH_STACK) { overflow++; return; }
+        stack[sp++] = N.right;
+        cur = N.left;
+      } else if (hl || hr) {
+        cur = hl ? N.left : N.right;
+      } else {
+        if (sp == 0) break;
+        cur = stack[--sp];
+      }
+    }
+    if (best == 0x7FFFFFFF) return;
+    h.set_lim(bz);
+    h.idx = best; h.by = b1; h.bz = b2;
+    after = best;
+  }
+}
+
+// existsIntersection through the tree: true as soon as one triangle's reference test accepts
+__device__ __forceinline__ bool bvh_any(const DeviceScene& sc, const BvhNode* __restrict__ nodes, const BvhRay& r,
+                                        float max_t, uint32_t& overflow) {
+  // t of an accepted triangle is <= max_t; its true distance can exceed that by the filter's slack
+  const float bound = fabsf(max_t) * 1.05f + 4.0f * r.delta + 1e-30f;
+  int stack[BVH_STACK];
+  int sp = 0;
+  int cur = sc.n_tris > 1 ? 0 : -1;
+  for (;;) {
+    if (cur < 0) {
+      const int i = -1 - cur;
+      float t, z, x1, x2;
+      if (bvh_leaf(sc, r, i, t, z, x1, x2) && t <= max_t && (x1 + x2) <= 1.0f) return true;  // :75-77
+      if (sp == 0) return false;
+      cur = stack[--sp];
+      continue;
+    }
+    const BvhNode N = nodes[cur];
+    float tl, tr;
+    const bool hl = slab(N.lmin, N.lmax, r.oo, r.inv, bound, tl);
+    const bool hr = slab(N.rmin, N.rmax, r.oo, r.inv, bound, tr);
+    if (hl && hr) {
+      if (sp >= BVH_STACK) { overflow++; return false; }
+      stack[sp++] = N.right;
+      cur = N.left;
+    } else if (hl || hr) {
+      cur = hl ? N.left : N.right;
+    } else {
+      if (sp == 0) return false;
+      cur = stack[--sp];
+    }
+  }
+}
+
+}  // namespace mipt

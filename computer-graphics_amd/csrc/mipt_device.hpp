@@ -14,6 +14,8 @@
 
 namespace mipt {
 
+constexpr int BLOCK = 256;  // threads per workgroup of every kernel
+
 // ---------------------------------------------------------------------------------------
 // HBM layout of a scene (built once per scene by mipt_scene_create)
 //
@@ -55,17 +57,21 @@ struct __attribute__((aligned(16))) SphereRec {
   uint32_t material, pad0, pad1, pad2;
 };
 
+struct BvhNode;
+
 struct DeviceScene {
+  const BvhNode* bvh;  // LBVH over the triangles, or null: linear scan
   const TriRec* tris;
   const ShadeRec* shade;  // n_tris triangle records followed by n_spheres sphere records
   const SphereRec* spheres;
   int n_tris;
   int n_spheres;
+  float scale;  // largest |coordinate| of a triangle vertex (slack of the tree traversal)
 };
 
 enum StatSlot {
   ST_PATHS = 0, ST_CLOSEST, ST_SHADOW, ST_TESTS, ST_GATE, ST_SPHERE, ST_FOG, ST_DIFFUSE, ST_MIRROR,
-  ST_GLASS, ST_COUNT
+  ST_GLASS, ST_BVH_REDO, ST_BVH_OVERFLOW, ST_COUNT
 };
 
 #define MIPT_CONST __attribute__((address_space(4)))

@@ -11,11 +11,10 @@
 // contraction, so there is no MFMA. Compiled with -ffp-contract=off (see mipt_device.hpp).
 #pragma once
 
-#include "mipt_device.hpp"
+#include "mipt_bvh.hpp"
 
 namespace mipt {
 
-constexpr int BLOCK = 256;
 // samples per work item of the path kernel, and the size of its persistent grid (256 CUs x 8)
 #ifndef MIPT_ITEM_SAMPLES
 #define MIPT_ITEM_SAMPLES 16
@@ -105,6 +104,35 @@ __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d
   }
 }
 
+// One closestIntersection / existsIntersection query against the scene: the linear scan for
+// small scenes, the LBVH traversal (mipt_bvh.hpp) when the scene carries a tree. `redo` counts
+// rays sent through the exhaustive traversal, `overflow` rays whose stack or hit list was too
+// small even there (must stay 0).
+template <bool STATS, bool BVH>
+__device__ __forceinline__ void scene_query(const DeviceScene& sc, V4 o, V4 d, bool shadow, HitAcc& h,
+                                            uint32_t& n_tests, uint32_t& n_gate, uint32_t& redo,
+                                            uint32_t& overflow) {
+  if (!BVH) {  // kernels are instantiated per kind of scene: the linear ones carry no traversal stack
+    scan_triangles<STATS>(sc, o, d, shadow, h, n_tests, n_gate);
+    return;
+  }
+  const BvhRay r = bvh_ray(sc, o, d);
+  if (shadow) {
+    if (bvh_any(sc, sc.bvh, r, h.lim, overflow)) {
+      h.set_lim(-1.0f);
+      h.idx = 1;
+    }
+  } else {
+    const HitAcc h0 = h;
+    if (!bvh_closest(sc, sc.bvh, r, h, overflow)) {
+      h = h0;
+      redo++;
+      bvh_closest_exhaustive(sc, sc.bvh, r, h, overflow);
+    }
+  }
+}
+
+template <bool BVH>
 __global__ __launch_bounds__(BLOCK) void k_closest_hit(DeviceScene sc, const float4* __restrict__ origin,
                                                        const float4* __restrict__ dir, size_t n_rays,
                                                        int32_t* __restrict__ tri_idx, float* __restrict__ t_out,
@@ -116,8 +144,8 @@ __global__ __launch_bounds__(BLOCK) void k_closest_hit(DeviceScene sc, const flo
   HitAcc h;
   h.set_lim(3.402823466e+38f);
   h.idx = -1; h.by = 0.f; h.bz = 0.f;
-  uint32_t n_tests = 0, n_gate = 0;
-  scan_triangles<false>(sc, o, d, false, h, n_tests, n_gate);
+  uint32_t n_tests = 0, n_gate = 0, redo = 0, overflow = 0;
+  scene_query<false, BVH>(sc, o, d, false, h, n_tests, n_gate, redo, overflow);
   V4 pos = {0, 0, 0, 0}, nrm;
   bool sphere_hit = false;
   for (int s = 0; s < sc.n_spheres; ++s) {
@@ -142,6 +170,7 @@ __global__ __launch_bounds__(BLOCK) void k_closest_hit(DeviceScene sc, const flo
   }
 }
 
+template <bool BVH>
 __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4* __restrict__ origin,
                                                    const float4* __restrict__ dir,
                                                    const float* __restrict__ max_t, size_t n_rays,
@@ -153,8 +182,8 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
   HitAcc h;
   h.set_lim(max_t[i]);
   h.idx = 0; h.by = 0.f; h.bz = 0.f;
-  uint32_t n_tests = 0, n_gate = 0;
-  scan_triangles<false>(sc, o, d, true, h, n_tests, n_gate);
+  uint32_t n_tests = 0, n_gate = 0, redo = 0, overflow = 0;
+  scene_query<false, BVH>(sc, o, d, true, h, n_tests, n_gate, redo, overflow);
   occluded[i] = (uint8_t)h.idx;
 }
 
@@ -186,7 +215,7 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
 #endif
 #define MIPT_PATHS_OCC __attribute__((amdgpu_waves_per_eu(MIPT_WAVES_PER_EU, MIPT_WAVES_PER_EU)))
 
-template <int RNG_MODE, bool STATS, bool LIST>
+template <int RNG_MODE, bool STATS, bool LIST, bool BVH>
 __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a) {
   extern __shared__ uint32_t lds_stack[];  // [max_depth][BLOCK] tags, then sphere normals
   const int tid = threadIdx.x;
@@ -310,11 +339,11 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
     h.set_lim(shadow ? shadow_max : 3.402823466e+38f);
     h.idx = shadow ? 0 : -1;
     h.by = 0.f; h.bz = 0.f;
-    uint32_t n_tests = 0, n_gate = 0;
-    scan_triangles<STATS>(a.sc, o, d, shadow, h, n_tests, n_gate);
+    uint32_t n_tests = 0, n_gate = 0, redo = 0, overflow = 0;
+    scene_query<STATS, BVH>(a.sc, o, d, shadow, h, n_tests, n_gate, redo, overflow);
     if (STATS || LIST) {
       st[shadow ? ST_SHADOW : ST_CLOSEST]++;
-      if (STATS) { st[ST_TESTS] += n_tests; st[ST_GATE] += n_gate; }
+      if (STATS) { st[ST_TESTS] += n_tests; st[ST_GATE] += n_gate; st[ST_BVH_REDO] += redo; st[ST_BVH_OVERFLOW] += overflow; }
     }
 
     bool path_done = false;
@@ -581,6 +610,7 @@ __global__ __launch_bounds__(BLOCK) void k_selfcheck_rcp(unsigned long long* out
   atomicMax(out + 1, (unsigned long long)worst);
 }
 
+template <bool BVH>
 __global__ __launch_bounds__(BLOCK) void k_selfcheck_scan(DeviceScene sc, unsigned long long n_rays, uint32_t seed,
                                                           unsigned long long* out) {
   const unsigned long long gid = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -614,12 +644,17 @@ __global__ __launch_bounds__(BLOCK) void k_selfcheck_scan(DeviceScene sc, unsign
     uint32_t nt = 0, ng = 0;
     scan_triangles<false, SCAN_LITERAL>(sc, o, d, mode != 0, e, nt, ng);
     scan_triangles<false, SCAN_FAST>(sc, o, d, mode != 0, f, nt, ng);
-    scan_triangles<false, SCAN_TWO_PHASE>(sc, o, d, mode != 0, g, nt, ng);
+    uint32_t redo = 0, overflow = 0;
+    scene_query<false, BVH>(sc, o, d, mode != 0, g, nt, ng, redo, overflow);  // two-phase scan, or the LBVH
+    if (redo) atomicAdd(out + 4, (unsigned long long)redo);
+    if (overflow) atomicAdd(out + 5, (unsigned long long)overflow);
     auto same = [](const HitAcc& a, const HitAcc& b) {
       return a.idx == b.idx && __float_as_uint(a.lim) == __float_as_uint(b.lim) &&
              __float_as_uint(a.by) == __float_as_uint(b.by) && __float_as_uint(a.bz) == __float_as_uint(b.bz);
     };
-    if (!same(f, e) || !same(g, e)) atomicAdd(out + 2 + mode, 1ull);
+    // any-hit through the tree reports only whether a triangle accepts, not which
+    const bool g_ok = (mode && sc.bvh) ? (g.idx == e.idx) : same(g, e);
+    if (!same(f, e) || !g_ok) atomicAdd(out + 2 + mode, 1ull);
   }
 }
 

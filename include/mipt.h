@@ -135,6 +135,8 @@ typedef struct MiptStats {
   uint64_t diffuse_bounces; /* bounceDiffuse calls */
   uint64_t mirror_bounces;  /* bounceMirror calls */
   uint64_t glass_bounces;   /* bounceGlass calls */
+  uint64_t bvh_redo;        /* LBVH scenes: rays re-run through the exhaustive traversal */
+  uint64_t bvh_overflow;    /* LBVH scenes: rays whose stack / hit list overflowed (must be 0) */
   double kernel_ms;        /* device time of the last render call's path kernel */
 } MiptStats;
 
@@ -163,6 +165,12 @@ const char* mipt_version(void);
 int mipt_scene_create(const MiptTriangle* tris, size_t n_tris,
                       const MiptSphere* spheres, size_t n_spheres,
                       int device, MiptScene** out);
+/* Scenes of MIPT_BVH_MIN_TRIS triangles or more get an LBVH built on the GPU at creation
+ * (the reference has none: main.cpp:19 lists "KD trees?" as a TODO and always scans linearly);
+ * results are those of the linear scan. Returns 1 / 0, the node count in *n_nodes (nullable)
+ * and the build time in *build_ms (nullable). */
+#define MIPT_BVH_MIN_TRIS 256
+int mipt_scene_has_bvh(MiptScene* scene, uint64_t* n_nodes, double* build_ms);
 void mipt_scene_destroy(MiptScene* scene);
 
 /* Batch closestIntersection (intersections.cpp:6-55). Host pointers.
@@ -223,10 +231,12 @@ int mipt_get_stats(MiptScene* scene, MiptStats* out);
  * correctly-rounded reciprocal against IEEE 1.0f/b for all 2^32 floats and (2) its fast triangle
  * scan against the literal reference arithmetic on n_rays generated rays (camera rays, incoherent
  * interior rays, origins on triangle surfaces and edges), closest-hit and any-hit rule.
+ * For a scene with an LBVH, (2) compares the tree traversal with the literal linear scan.
  * out[0] = reciprocal mismatches, out[1] = worst error of the hardware reciprocal estimate in
- * 2^-10 ulp, out[2] / out[3] = rays whose closest-hit / any-hit result differs. All of
- * out[0], out[2], out[3] must be 0. */
-int mipt_debug_selfcheck(MiptScene* scene, uint64_t n_rays, uint32_t seed, uint64_t out[4]);
+ * 2^-10 ulp, out[2] / out[3] = rays whose closest-hit / any-hit result differs, out[4] = rays
+ * re-run through the exhaustive tree traversal, out[5] = traversal overflows, out[6..7] = 0.
+ * All of out[0], out[2], out[3], out[5] must be 0. */
+int mipt_debug_selfcheck(MiptScene* scene, uint64_t n_rays, uint32_t seed, uint64_t out[8]);
 
 /* The (seed, pixel, sample) -> 32-bit key shared by both per-path RNG modes.
  * pixel = x*height + y. Exposed so that hosts and tests can reproduce streams. */

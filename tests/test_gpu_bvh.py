@@ -1,0 +1,118 @@
+"""GPU parity of the LBVH path (scenes of MIPT_BVH_MIN_TRIS triangles or more) against the
+reference's linear scan: on the device against the literal scan for millions of rays, and
+through the C ABI against the CPU oracle on smaller batches. Bit-exact: index, distance,
+position, occlusion."""
+import numpy as np
+import pytest
+
+import bigscenes
+import raygen
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def api(pkg):
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    pkg.abi.load_library()
+    return pkg.api
+
+
+@pytest.fixture(scope="module")
+def dtype(pkg):
+    return pkg.abi.TRIANGLE_DTYPE
+
+
+def scenes(O, dtype):
+    return {
+        "mesh9k": bigscenes.mesh_in_room(O, dtype, cells=48, nu=64, nv=32),            # 8 714
+        "mesh140k": bigscenes.mesh_in_room(O, dtype, cells=192, nu=256, nv=128),       # 139 274
+        "soup20k": np.concatenate([bigscenes.room(O), bigscenes.soup(dtype, 20000)]),
+    }
+
+
+@pytest.mark.parametrize("name", ["mesh9k", "mesh140k", "soup20k"])
+def test_tree_equals_literal_scan_on_device(api, O, dtype, name):
+    tris = scenes(O, dtype)[name]
+    sc = api.Scene(tris)
+    has, n_nodes, build_ms = sc.bvh_info()
+    assert has and n_nodes == len(tris) - 1
+    n_rays = (1 << 22) if len(tris) < 50000 else (1 << 20)
+    rcp_bad, _, closest_bad, any_bad = sc.selfcheck(n_rays, seed=5)
+    redo, overflow = sc.last_selfcheck_bvh
+    sc.close()
+    print(f"{name}: {len(tris)} triangles, build {build_ms:.2f} ms, {n_rays} rays: "
+          f"closest_bad={closest_bad} any_bad={any_bad} redo={redo} overflow={overflow}")
+    assert rcp_bad == 0 and overflow == 0
+    assert closest_bad == 0 and any_bad == 0, (closest_bad, any_bad)
+    assert redo < n_rays // 100  # the exhaustive traversal is the exception
+
+
+def test_threshold_and_small_trees(api, O, dtype):
+    # just below the threshold: linear scan; at and just above it: a tree
+    soup = np.concatenate([bigscenes.room(O), bigscenes.soup(dtype, 300, seed=9, size=0.2)])
+    for n in (255, 256, 257):
+        sc = api.Scene(soup[:n])
+        assert sc.bvh_info()[0] == (n >= 256)
+        _, _, closest_bad, any_bad = sc.selfcheck(1 << 18, seed=n)
+        assert (closest_bad, any_bad) == (0, 0)
+        assert sc.last_selfcheck_bvh[1] == 0
+        sc.close()
+
+
+def test_identical_triangles_share_one_morton_key(api, O, dtype):
+    # 20 copies of one triangle: equal Morton keys, and every hit is a 20-way exact tie. The
+    # reference's rule `t <= min -> min = |x.x|` gives it to the last copy when t <= |x.x| and to
+    # the first when rounding left t above |x.x|; never to a copy in between
+    one = bigscenes.soup(dtype, 1, seed=3, size=0.3)
+    tris = np.concatenate([bigscenes.room(O), np.repeat(one, 20)])
+    tris = np.concatenate([tris, bigscenes.soup(dtype, 400, seed=4)])
+    sc = api.Scene(tris)
+    assert sc.bvh_info()[0]
+    o, d = raygen.interior_rays(1 << 14)
+    idx, t, pos = sc.closest_hit(o, d)
+    oidx, ot, opos = O.closest_hit(tris, None, o, d)
+    sc.close()
+    assert np.array_equal(idx, oidx)
+    copies = idx[(idx >= 10) & (idx < 30)]
+    assert len(copies) > 50 and np.all((copies == 29) | (copies == 10)) and (copies == 29).any()
+
+
+@pytest.mark.parametrize("name", ["mesh9k", "soup20k"])
+def test_tree_queries_match_oracle(api, O, dtype, name):
+    tris = scenes(O, dtype)[name]
+    sc = api.Scene(tris)
+    n = 1 << 13
+    for kind, (o, d) in {"primary": raygen.primary_rays(n), "interior": raygen.interior_rays(n),
+                         "surface": raygen.surface_rays(tris, n)}.items():
+        idx, t, pos = sc.closest_hit(o, d)
+        oidx, ot, opos = O.closest_hit(tris, None, o, d)
+        assert np.array_equal(idx, oidx), (kind, np.count_nonzero(idx != oidx))
+        hit = oidx >= 0
+        assert np.array_equal(bits(t[hit]), bits(ot[hit])), kind
+        assert np.array_equal(bits(pos[hit]), bits(opos[hit])), kind
+    o, d, r = raygen.shadow_rays(tris, n)
+    assert np.array_equal(sc.any_hit(o, d, r), O.any_hit(tris, o, d, r))
+    sc.close()
+
+
+def test_tree_render_matches_oracle(api, O, dtype):
+    # whole paths through a tree scene: same image sums as the oracle's linear scan
+    tris = scenes(O, dtype)["mesh9k"]
+    W = H = 24
+    cam, light = api.default_camera(W), api.default_light(True)
+    p = api.default_params(W, H, flags=1)
+    sc = api.Scene(tris)
+    img = sc.render_accumulate(cam, light, p, 0, 4)
+    st = sc.stats()
+    sc.close()
+    ref, ost = O.render_accumulate(tris, None, cam, light, p, 0, 4)
+    assert st.bvh_overflow == 0
+    assert (st.closest_rays, st.shadow_rays) == (ost.closest_rays, ost.shadow_rays)
+    same = (bits(img) == bits(ref)).all(axis=2).mean()
+    assert same > 0.995, same
