@@ -152,7 +152,8 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
                              size_t n_spheres, int device, MiptScene* s) {
   s->device = device;
   HIP_TRY(hipSetDevice(device));
-  std::vector<TriRec> tr(n_tris ? n_tris : 1);
+  std::vector<TriRec> tr(n_tris + 2);  // two records of padding: the scan prefetches ahead
+  memset(tr.data(), 0, tr.size() * sizeof(TriRec));
   std::vector<ShadeRec> sh(n_tris + n_spheres ? n_tris + n_spheres : 1);
   std::vector<SphereRec> sp(n_spheres ? n_spheres : 1);
   float scale = 0.f;
@@ -214,12 +215,12 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
   HIP_TRY(hipMalloc(&s->d_tris, tr.size() * sizeof(TriRec)));
   HIP_TRY(hipMalloc(&s->d_shade, sh.size() * sizeof(ShadeRec)));
   HIP_TRY(hipMalloc(&s->d_spheres, sp.size() * sizeof(SphereRec)));
-  HIP_TRY(hipMalloc(&s->d_stats, ST_COUNT * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&s->d_stats, (ST_COUNT + PF_COUNT) * sizeof(unsigned long long)));
   HIP_TRY(hipMalloc(&s->d_queue, 256));
   HIP_TRY(hipMemcpy(s->d_tris, tr.data(), tr.size() * sizeof(TriRec), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s->d_shade, sh.data(), sh.size() * sizeof(ShadeRec), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s->d_spheres, sp.data(), sp.size() * sizeof(SphereRec), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(s->d_stats, 0, ST_COUNT * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(s->d_stats, 0, (ST_COUNT + PF_COUNT) * sizeof(unsigned long long)));
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
   s->d.tris = s->d_tris;
@@ -479,7 +480,10 @@ extern "C" int mipt_render_accumulate_dev(MiptScene* s, const MiptCamera* cam, c
   const unsigned grid = (unsigned)(batches / 4u + 1u < PERSISTENT_BLOCKS ? batches / 4u + 1u : PERSISTENT_BLOCKS);
   HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(uint32_t), st));
   const bool stats = (p->flags & MIPT_FLAG_STATS) != 0;
-  if (stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, ST_COUNT * sizeof(unsigned long long), st));
+  if (stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, (ST_COUNT + PF_COUNT) * sizeof(unsigned long long), st));
+#ifdef MIPT_PROFILE_SECTIONS
+  HIP_TRY(hipMemsetAsync(s->d_stats + ST_COUNT, 0, PF_COUNT * sizeof(unsigned long long), st));
+#endif
   HIP_TRY(hipEventRecord(s->ev0, st));
   launch_paths<false>(a, dim3(grid), stack_bytes(s, p), st);
   HIP_TRY(hipGetLastError());
@@ -538,7 +542,7 @@ extern "C" int mipt_trace_paths(MiptScene* s, const MiptCamera* cam, const MiptL
   a.rgb = drgb.as<float>();
   a.counts = dcnt.as<uint32_t>();
   const bool stats = (p->flags & MIPT_FLAG_STATS) != 0;
-  if (stats) HIP_TRY(hipMemset(s->d_stats, 0, ST_COUNT * sizeof(unsigned long long)));
+  if (stats) HIP_TRY(hipMemset(s->d_stats, 0, (ST_COUNT + PF_COUNT) * sizeof(unsigned long long)));
   HIP_TRY(hipEventRecord(s->ev0, nullptr));
   launch_paths<true>(a, dim3(grid_for(n_paths)), stack_bytes(s, p), nullptr);
   HIP_TRY(hipGetLastError());
@@ -562,6 +566,19 @@ extern "C" int mipt_get_stats(MiptScene* s, MiptStats* out) {
   HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
   out->kernel_ms = ms;
   out->paths = s->last_paths;
+#ifdef MIPT_PROFILE_SECTIONS
+  {
+    unsigned long long pf[PF_COUNT];
+    HIP_TRY(hipMemcpy(pf, s->d_stats + ST_COUNT, sizeof pf, hipMemcpyDeviceToHost));
+    static const char* names[PF_COUNT] = {"queue", "raygen", "phase1", "phase2", "hit", "terminal", "scatter",
+                                          "diffuse", "mirror", "glass", "renorm", "unwind"};
+    double tot = 0;
+    for (int k = 0; k < PF_COUNT; ++k) tot += (double)pf[k];
+    fprintf(stderr, "[mipt sections, %% of wave time]");
+    for (int k = 0; k < PF_COUNT; ++k) fprintf(stderr, " %s %.1f", names[k], 100.0 * (double)pf[k] / (tot > 0 ? tot : 1));
+    fprintf(stderr, " (total %.3g ticks)\n", tot);
+  }
+#endif
   if (s->stats_valid) {
     unsigned long long h[ST_COUNT];
     HIP_TRY(hipMemcpy(h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));

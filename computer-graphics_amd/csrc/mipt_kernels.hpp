@@ -57,6 +57,32 @@ struct PathArgs {
 
 // ---------------------------------------------------------------------------------------
 
+// Developer build (-DMIPT_PROFILE_SECTIONS): wall time of the path kernel's sections, summed over
+// waves in units of the constant 100 MHz shader clock. One active lane per wave adds the time since
+// the previous mark to the section's LDS counter; mipt_get_stats prints the totals.
+enum ProfSection {
+  PF_QUEUE = 0, PF_RAYGEN, PF_PHASE1, PF_PHASE2, PF_HIT, PF_TERMINAL, PF_SCATTER, PF_DIFFUSE, PF_MIRROR,
+  PF_GLASS, PF_RENORM, PF_UNWIND, PF_COUNT
+};
+#ifdef MIPT_PROFILE_SECTIONS
+struct Prof {
+  uint32_t last;
+  uint32_t* lds;
+  __device__ __forceinline__ void start() { last = (uint32_t)__builtin_readcyclecounter(); }
+  __device__ __forceinline__ void mark(int k) {
+    const uint32_t now = (uint32_t)__builtin_readcyclecounter();
+    if (lds && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(lds + k, now - last);
+    last = now;
+  }
+};
+#else
+struct Prof {
+  uint32_t* lds;
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void mark(int) {}
+};
+#endif
+
 // The linear scan of closestIntersection / existsIntersection, three ways with identical results:
 //   SCAN_LITERAL    the reference's arithmetic for every triangle, in index order;
 //   SCAN_FAST       the same with the estimate-based gate and rcp_exact (tri_test<FAST>);
@@ -74,7 +100,7 @@ enum ScanMode { SCAN_LITERAL = 0, SCAN_FAST = 1, SCAN_TWO_PHASE = 2 };
 
 template <bool STATS, int MODE = (STATS ? SCAN_FAST : MIPT_SCAN_MODE)>
 __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d, bool shadow, HitAcc& h,
-                                               uint32_t& n_tests, uint32_t& n_gate) {
+                                               uint32_t& n_tests, uint32_t& n_gate, Prof& prof) {
   const TriRec MIPT_CONST* tris = as_constant(sc.tris);
   const float px = -d.x, py = -d.y, pz = -d.z;  // vec3(-ray.direction), intersections.cpp:20
   const int n = sc.n_tris;
@@ -89,8 +115,12 @@ __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d
   for (int base = 0; base < n; base += 32) {
     const int m = (n - base < 32) ? n - base : 32;
     uint32_t mask = 0;
+    // unrolled so that the scalar loads of the next record overlap the arithmetic of this one
+    // (rolled, every triangle waits out its own load: -9 % paths/s)
+#pragma unroll 4
     for (int j = 0; j < m; ++j)
       if (tri_candidate(tris + base + j, o.x, o.y, o.z, d.x, d.y, d.z, Dm)) mask |= 1u << j;
+    prof.mark(PF_PHASE1);
     while (__any(mask != 0)) {
       if (mask != 0) {
         const int i = base + __ffs((int)mask) - 1;
@@ -101,6 +131,7 @@ __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d
         tri_test<false, true>(&T, i, o.x, o.y, o.z, px, py, pz, shadow, h, n_tests, n_gate);
       }
     }
+    prof.mark(PF_PHASE2);
   }
 }
 
@@ -111,9 +142,9 @@ __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d
 template <bool STATS, bool BVH>
 __device__ __forceinline__ void scene_query(const DeviceScene& sc, V4 o, V4 d, bool shadow, HitAcc& h,
                                             uint32_t& n_tests, uint32_t& n_gate, uint32_t& redo,
-                                            uint32_t& overflow) {
+                                            uint32_t& overflow, Prof& prof) {
   if (!BVH) {  // kernels are instantiated per kind of scene: the linear ones carry no traversal stack
-    scan_triangles<STATS>(sc, o, d, shadow, h, n_tests, n_gate);
+    scan_triangles<STATS>(sc, o, d, shadow, h, n_tests, n_gate, prof);
     return;
   }
   const BvhRay r = bvh_ray(sc, o, d);
@@ -145,7 +176,8 @@ __global__ __launch_bounds__(BLOCK) void k_closest_hit(DeviceScene sc, const flo
   h.set_lim(3.402823466e+38f);
   h.idx = -1; h.by = 0.f; h.bz = 0.f;
   uint32_t n_tests = 0, n_gate = 0, redo = 0, overflow = 0;
-  scene_query<false, BVH>(sc, o, d, false, h, n_tests, n_gate, redo, overflow);
+  Prof prof{};
+  scene_query<false, BVH>(sc, o, d, false, h, n_tests, n_gate, redo, overflow, prof);
   V4 pos = {0, 0, 0, 0}, nrm;
   bool sphere_hit = false;
   for (int s = 0; s < sc.n_spheres; ++s) {
@@ -183,7 +215,8 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
   h.set_lim(max_t[i]);
   h.idx = 0; h.by = 0.f; h.bz = 0.f;
   uint32_t n_tests = 0, n_gate = 0, redo = 0, overflow = 0;
-  scene_query<false, BVH>(sc, o, d, true, h, n_tests, n_gate, redo, overflow);
+  Prof prof{};
+  scene_query<false, BVH>(sc, o, d, true, h, n_tests, n_gate, redo, overflow, prof);
   occluded[i] = (uint8_t)h.idx;
 }
 
@@ -262,6 +295,14 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   uint32_t* tags = lds_stack;
   float* sph_n = reinterpret_cast<float*>(lds_stack + (size_t)P.max_depth * BLOCK);
   const bool fog = P.fog_sigma_t > 0.f;
+  Prof prof{};
+#ifdef MIPT_PROFILE_SECTIONS
+  __shared__ uint32_t prof_lds[PF_COUNT];
+  if (tid < PF_COUNT) prof_lds[tid] = 0;
+  __syncthreads();
+  prof.lds = prof_lds;
+#endif
+  prof.start();
 
   for (;;) {
     if (!LIST) {
@@ -315,6 +356,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       if (drained) break;
       continue;
     }
+    prof.mark(PF_QUEUE);
     if (have) {
     if (fresh) {
       // main.cpp:124-133: two draws jitter the pixel, direction = Rx*Ry*d, not normalised
@@ -334,13 +376,14 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       if (STATS || LIST) st[ST_PATHS]++;
     }
 
+    prof.mark(PF_RAYGEN);
     // ---- one ray/scene query: closestIntersection, or existsIntersection for a shadow ray
     HitAcc h;
     h.set_lim(shadow ? shadow_max : 3.402823466e+38f);
     h.idx = shadow ? 0 : -1;
     h.by = 0.f; h.bz = 0.f;
     uint32_t n_tests = 0, n_gate = 0, redo = 0, overflow = 0;
-    scene_query<STATS, BVH>(a.sc, o, d, shadow, h, n_tests, n_gate, redo, overflow);
+    scene_query<STATS, BVH>(a.sc, o, d, shadow, h, n_tests, n_gate, redo, overflow, prof);
     if (STATS || LIST) {
       st[shadow ? ST_SHADOW : ST_CLOSEST]++;
       if (STATS) { st[ST_TESTS] += n_tests; st[ST_GATE] += n_gate; st[ST_BVH_REDO] += redo; st[ST_BVH_OVERFLOW] += overflow; }
@@ -396,6 +439,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
         V4 nd = d;
         bool renorm = false, offset_origin = false;
         const bool terminal = depth >= P.max_depth || rng_next<RNG_MODE>(rng) <= P.rr_prob;  // :80
+        prof.mark(PF_HIT);
         if (terminal) {
           // pathtracer.cpp:81-93 + directLight (light.cpp:13-31)
           V4 lp;
@@ -439,6 +483,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           nd = vecr; renorm = true;  // Ray ctor normalises again (ray.h:11-12)
           shadow_max = r;
           shadow = true;
+          prof.mark(PF_TERMINAL);
         } else if (medium) {
           // isotropic scattering, weight = single-scattering albedo
           const float u1 = rng_next<RNG_MODE>(rng);
@@ -452,6 +497,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           d = {rxy * cs, rxy * sn, z, 0.0f};
           tags[sp * BLOCK + tid] = TAG_FOG;
           sp++; depth++;
+          prof.mark(PF_SCATTER);
         } else {
           o = pos;  // pathtracer.cpp:100
           const uint32_t mat = sh.material;
@@ -481,12 +527,14 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
               q[0] = nrm.x; q[1] = nrm.y; q[2] = nrm.z; q[3] = nrm.w;
             }
             sp++; depth++;
+            prof.mark(PF_DIFFUSE);
           } else if (mat == MIPT_MAT_MIRROR) {
             // bounceMirror (pathtracer.cpp:21-27); weight 1, nothing to unwind
             if (STATS) st[ST_MIRROR]++;
             const float ct = dot4(nrm, d) * -1.0f;
             nd = add4(d, scale4(nrm, ct * 2.0f)); renorm = true;
             depth++;
+            prof.mark(PF_MIRROR);
           } else if (mat == MIPT_MAT_GLASS) {
             // bounceGlass (pathtracer.cpp:29-63)
             if (STATS) st[ST_GLASS]++;
@@ -510,6 +558,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
             renorm = true;
             tags[sp * BLOCK + tid] = TAG_GLASS;
             sp++; depth++;
+            prof.mark(PF_GLASS);
           } else if (mat == MIPT_MAT_SPECULAR) {
             // bounceSpecular (pathtracer.cpp:65-70); weight 1
             const float k2 = dot4(d, nrm) * 2.f;
@@ -523,6 +572,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           d = normalize4(nd);
           if (offset_origin) o = add4(o, scale4(d, 0.001f));  // pathtracer.cpp:14
         }
+        prof.mark(PF_RENORM);
       }
     }
 
@@ -559,7 +609,12 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       }
     }
     }  // if (have)
+    prof.mark(PF_UNWIND);
   }
+#ifdef MIPT_PROFILE_SECTIONS
+  __syncthreads();
+  if (tid < PF_COUNT && prof_lds[tid]) atomicAdd(a.stats + ST_COUNT + tid, (unsigned long long)prof_lds[tid]);
+#endif
 
   if (LIST) {
     if (list_i < a.n_paths) {
@@ -642,10 +697,11 @@ __global__ __launch_bounds__(BLOCK) void k_selfcheck_scan(DeviceScene sc, unsign
     f.set_lim(mode ? max_t : 3.402823466e+38f); f.idx = mode ? 0 : -1; f.by = f.bz = 0.f;
     e = f; g = f;
     uint32_t nt = 0, ng = 0;
-    scan_triangles<false, SCAN_LITERAL>(sc, o, d, mode != 0, e, nt, ng);
-    scan_triangles<false, SCAN_FAST>(sc, o, d, mode != 0, f, nt, ng);
+    Prof prof{};
+    scan_triangles<false, SCAN_LITERAL>(sc, o, d, mode != 0, e, nt, ng, prof);
+    scan_triangles<false, SCAN_FAST>(sc, o, d, mode != 0, f, nt, ng, prof);
     uint32_t redo = 0, overflow = 0;
-    scene_query<false, BVH>(sc, o, d, mode != 0, g, nt, ng, redo, overflow);  // two-phase scan, or the LBVH
+    scene_query<false, BVH>(sc, o, d, mode != 0, g, nt, ng, redo, overflow, prof);  // two-phase scan, or the LBVH
     if (redo) atomicAdd(out + 4, (unsigned long long)redo);
     if (overflow) atomicAdd(out + 5, (unsigned long long)overflow);
     auto same = [](const HitAcc& a, const HitAcc& b) {
