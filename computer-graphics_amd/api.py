@@ -162,6 +162,7 @@ class Scene:
         out = (C.c_uint64 * 8)()
         _check(self._lib.mipt_debug_selfcheck(self._h, n_rays, seed, C.byref(out)))
         self.last_selfcheck_bvh = (int(out[4]), int(out[5]))  # (exhaustive re-runs, overflows)
+        self.last_selfcheck_sincos = int(out[6])  # floats in [0, 2 pi] with a fused/plain sincos mismatch
         return int(out[0]), out[1] / 1024.0, int(out[2]), int(out[3])
 
     def bvh_info(self):

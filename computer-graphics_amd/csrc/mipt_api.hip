@@ -407,28 +407,41 @@ static void fill_args(PathArgs& a, const MiptScene* s, const MiptCamera* cam, co
   a.stats = s->d_stats;
 }
 
-static size_t stack_bytes(const MiptScene* s, const MiptParams* p) {
-  size_t per_level = (size_t)BLOCK * 4 * (s->d.n_spheres > 0 ? 5 : 1);
-  return per_level * (size_t)p->max_depth;
+static int scene_kind(const MiptScene* s) {
+  if (s->d.bvh) return SCENE_BVH;
+  return (s->d.n_tris + s->d.n_spheres <= LDS_TABLE_MAX) ? SCENE_LINEAR_LDS : SCENE_LINEAR;
 }
 
-template <bool LIST, bool BVH>
+// dynamic LDS of the path kernel: the per-lane vertex stack, then (small scenes) the record tables
+static size_t lds_bytes(const MiptScene* s, const MiptParams* p, PathArgs& a) {
+  size_t per_level = (size_t)BLOCK * 4 * (s->d.n_spheres > 0 ? 5 : 1);
+  size_t bytes = per_level * (size_t)p->max_depth;
+  a.lds_table_off = (uint32_t)(bytes / 4);
+  if (scene_kind(s) == SCENE_LINEAR_LDS)
+    bytes += (size_t)s->d.n_tris * sizeof(TriRec) + (size_t)(s->d.n_tris + s->d.n_spheres) * sizeof(ShadeRec);
+  return bytes;
+}
+
+template <bool LIST, int KIND>
 static void launch_paths_kind(const PathArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   const bool stats = (a.p.flags & MIPT_FLAG_STATS) != 0;
   const bool counter = a.p.rng_mode == MIPT_RNG_COUNTER;
   if (counter) {
-    if (stats) hipLaunchKernelGGL((k_paths<MIPT_RNG_COUNTER, true, LIST, BVH>), grid, dim3(BLOCK), lds, st, a);
-    else hipLaunchKernelGGL((k_paths<MIPT_RNG_COUNTER, false, LIST, BVH>), grid, dim3(BLOCK), lds, st, a);
+    if (stats) hipLaunchKernelGGL((k_paths<MIPT_RNG_COUNTER, true, LIST, KIND>), grid, dim3(BLOCK), lds, st, a);
+    else hipLaunchKernelGGL((k_paths<MIPT_RNG_COUNTER, false, LIST, KIND>), grid, dim3(BLOCK), lds, st, a);
   } else {
-    if (stats) hipLaunchKernelGGL((k_paths<MIPT_RNG_MINSTD_PATH, true, LIST, BVH>), grid, dim3(BLOCK), lds, st, a);
-    else hipLaunchKernelGGL((k_paths<MIPT_RNG_MINSTD_PATH, false, LIST, BVH>), grid, dim3(BLOCK), lds, st, a);
+    if (stats) hipLaunchKernelGGL((k_paths<MIPT_RNG_MINSTD_PATH, true, LIST, KIND>), grid, dim3(BLOCK), lds, st, a);
+    else hipLaunchKernelGGL((k_paths<MIPT_RNG_MINSTD_PATH, false, LIST, KIND>), grid, dim3(BLOCK), lds, st, a);
   }
 }
 
 template <bool LIST>
-static void launch_paths(const PathArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  if (a.sc.bvh) launch_paths_kind<LIST, true>(a, grid, lds, st);
-  else launch_paths_kind<LIST, false>(a, grid, lds, st);
+static void launch_paths(const MiptScene* s, const PathArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  switch (scene_kind(s)) {
+    case SCENE_BVH: launch_paths_kind<LIST, SCENE_BVH>(a, grid, lds, st); break;
+    case SCENE_LINEAR: launch_paths_kind<LIST, SCENE_LINEAR>(a, grid, lds, st); break;
+    default: launch_paths_kind<LIST, SCENE_LINEAR_LDS>(a, grid, lds, st); break;
+  }
 }
 
 extern "C" int mipt_render_accumulate_dev(MiptScene* s, const MiptCamera* cam, const MiptLight* light,
@@ -485,7 +498,8 @@ extern "C" int mipt_render_accumulate_dev(MiptScene* s, const MiptCamera* cam, c
   HIP_TRY(hipMemsetAsync(s->d_stats + ST_COUNT, 0, PF_COUNT * sizeof(unsigned long long), st));
 #endif
   HIP_TRY(hipEventRecord(s->ev0, st));
-  launch_paths<false>(a, dim3(grid), stack_bytes(s, p), st);
+  const size_t lds = lds_bytes(s, p, a);
+  launch_paths<false>(s, a, dim3(grid), lds, st);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev1, st));
   hipLaunchKernelGGL(k_reduce_chunks, dim3(grid_for(n_img)), dim3(BLOCK), 0, st, s->d_partial, n_sblocks, n_img,
@@ -544,7 +558,8 @@ extern "C" int mipt_trace_paths(MiptScene* s, const MiptCamera* cam, const MiptL
   const bool stats = (p->flags & MIPT_FLAG_STATS) != 0;
   if (stats) HIP_TRY(hipMemset(s->d_stats, 0, (ST_COUNT + PF_COUNT) * sizeof(unsigned long long)));
   HIP_TRY(hipEventRecord(s->ev0, nullptr));
-  launch_paths<true>(a, dim3(grid_for(n_paths)), stack_bytes(s, p), nullptr);
+  const size_t lds = lds_bytes(s, p, a);
+  launch_paths<true>(s, a, dim3(grid_for(n_paths)), lds, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev1, nullptr));
   HIP_TRY(hipDeviceSynchronize());
@@ -635,6 +650,8 @@ extern "C" int mipt_debug_selfcheck(MiptScene* s, uint64_t n_rays, uint32_t seed
   HIP_TRY(d.alloc(8 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(d.p, 0, 8 * sizeof(unsigned long long)));
   hipLaunchKernelGGL(k_selfcheck_rcp, dim3(4096 / BLOCK), dim3(BLOCK), 0, nullptr, d.as<unsigned long long>());
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_selfcheck_sincos, dim3(4096), dim3(BLOCK), 0, nullptr, d.as<unsigned long long>());
   HIP_TRY(hipGetLastError());
   if (n_rays) {
     const dim3 grid((unsigned)((n_rays + BLOCK - 1) / BLOCK));

@@ -191,10 +191,14 @@ __device__ __forceinline__ float rng_next(Rng& r) {
 // far finer than the final rounding to float, so this reproduces glibc's float results bit
 // for bit on the range the path uses (phi = 2*3.14*u, utils.cpp:12): verified exhaustively
 // for every float in [0, 6.28] on the build host.
-__device__ __forceinline__ void sincosf_glibc(float y, float& s_out, float& c_out) {
+// FUSED evaluates the same polynomials with fused multiply-adds (fewer double-precision
+// instructions); mipt_debug_selfcheck compares the two variants for every float in [0, 2 pi].
+template <bool FUSED>
+__device__ __forceinline__ void sincosf_glibc_impl(float y, float& s_out, float& c_out) {
   const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5,
                C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
   const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+  auto mad = [](double a, double b, double c) { return FUSED ? __builtin_fma(a, b, c) : a * b + c; };
   double x = (double)y;
   double sgn = 1.0, csgn = 1.0;
   int n = 0;
@@ -206,7 +210,7 @@ __device__ __forceinline__ void sincosf_glibc(float y, float& s_out, float& c_ou
   if (top >= 0x3F4u) {  // |y| >= pi/4 (compared on the top 12 bits, as glibc does)
     double r = x * 0x1.45F306DC9C883p+23;
     n = ((int32_t)r + 0x800000) >> 24;
-    x = x - (double)n * 0x1.921FB54442D18p0;
+    x = mad(-(double)n, 0x1.921FB54442D18p0, x);
     sgn = (n & 1) != ((n >> 1) & 1) ? -1.0 : 1.0;  // sign table {1,-1,-1,1}[n & 3]
     csgn = (n & 2) ? -1.0 : 1.0;                   // second coefficient table negates the cosine
   }
@@ -214,20 +218,23 @@ __device__ __forceinline__ void sincosf_glibc(float y, float& s_out, float& c_ou
   double x2 = x * x;
   // sine polynomial
   double x3 = xs * x2;
-  double s1 = S2 + x2 * S3;
+  double s1 = mad(x2, S3, S2);
   double x7 = x3 * x2;
-  double sp = xs + x3 * S1;
-  float sin_poly = (float)(sp + x7 * s1);
+  double sp = mad(x3, S1, xs);
+  float sin_poly = (float)mad(x7, s1, sp);
   // cosine polynomial
   double x4 = x2 * x2;
-  double c2 = csgn * C3 + x2 * (csgn * C4);
-  double c1 = csgn * C0 + x2 * (csgn * C1);
+  double c2 = mad(x2, csgn * C4, csgn * C3);
+  double c1 = mad(x2, csgn * C1, csgn * C0);
   double x6 = x4 * x2;
-  double cp = c1 + x4 * (csgn * C2);
-  float cos_poly = (float)(cp + x6 * c2);
+  double cp = mad(x4, csgn * C2, c1);
+  float cos_poly = (float)mad(x6, c2, cp);
   // sinf uses polynomial (n & 1), cosf polynomial ((n ^ 1) & 1)
   s_out = (n & 1) ? cos_poly : sin_poly;
   c_out = (n & 1) ? sin_poly : cos_poly;
+}
+__device__ __forceinline__ void sincosf_glibc(float y, float& s_out, float& c_out) {
+  sincosf_glibc_impl<true>(y, s_out, c_out);
 }
 
 // powf(x, 5.0f) (pathtracer.cpp:47). x^5 in double rounded once to float is the correctly
@@ -239,10 +246,62 @@ __device__ __forceinline__ float pow5f(float x) {
   return (float)((d2 * d2) * d);
 }
 
-// Transcendentals of the fog (which has no reference code): evaluated in double and rounded
-// once to float, so that host and device libms agree on the float result.
-__device__ __forceinline__ float fog_logf(float x) { return (float)log((double)x); }
-__device__ __forceinline__ float fog_expf(float x) { return (float)exp((double)x); }
+// Transcendentals of the fog (which has no reference code): fixed sequences of binary32
+// operations with explicit fused multiply-adds, so the host restatement and the device agree bit
+// for bit whatever their libms do. Accuracy ~1 ulp (Cephes' single-precision argument reduction
+// and polynomials); the polynomial and its evaluation order are part of the fog's definition here.
+__host__ __device__ __forceinline__ float fog_bits_to_float(uint32_t u) {
+  float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  f = __uint_as_float(u);
+#else
+  memcpy(&f, &u, 4);
+#endif
+  return f;
+}
+__host__ __device__ __forceinline__ float fog_expf(float x) {
+  if (!(x > -87.0f)) return 0.0f;
+  if (x > 88.0f) x = 88.0f;
+  const float k = __builtin_rintf(x * 1.44269504088896341f);
+  float r = __builtin_fmaf(k, -0.693359375f, x);
+  r = __builtin_fmaf(k, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+  const float y = __builtin_fmaf(p, r * r, r) + 1.0f;
+  return y * fog_bits_to_float((uint32_t)((int32_t)k + 127) << 23);
+}
+// x > 0 and normal (the fog calls it on 1 - u, u in [0, 1))
+__host__ __device__ __forceinline__ float fog_logf(float x) {
+  if (!(x > 0.0f)) return -__builtin_inff();
+  uint32_t ix;
+#if defined(__HIP_DEVICE_COMPILE__)
+  ix = __float_as_uint(x);
+#else
+  memcpy(&ix, &x, 4);
+#endif
+  int32_t e = (int32_t)(ix >> 23) - 126;  // x = m 2^e, m in [0.5, 1)
+  float m = fog_bits_to_float((ix & 0x007FFFFFu) | 0x3F000000u);
+  if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+  const float z = m * m;
+  float p = 7.0376836292e-2f;
+  p = __builtin_fmaf(p, m, -1.1514610310e-1f);
+  p = __builtin_fmaf(p, m, 1.1676998740e-1f);
+  p = __builtin_fmaf(p, m, -1.2420140846e-1f);
+  p = __builtin_fmaf(p, m, 1.4249322787e-1f);
+  p = __builtin_fmaf(p, m, -1.6668057665e-1f);
+  p = __builtin_fmaf(p, m, 2.0000714765e-1f);
+  p = __builtin_fmaf(p, m, -2.4999993993e-1f);
+  p = __builtin_fmaf(p, m, 3.3333331174e-1f);
+  float y = (p * m) * z;
+  const float fe = (float)e;
+  y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+  y = __builtin_fmaf(z, -0.5f, y);
+  return __builtin_fmaf(fe, 0.693359375f, m + y);
+}
 
 // ---------------------------------------------------------------------------------------
 // ray / triangle test, intersections.cpp:11-37 and :61-82

@@ -52,6 +52,7 @@ struct PathArgs {
   uint32_t n_paths;
   float* rgb;
   uint32_t* counts;
+  uint32_t lds_table_off;  // SCENE_LINEAR_LDS: dword offset of the record tables in dynamic LDS
   unsigned long long* stats;  // ST_COUNT device counters, STATS builds only
 };
 
@@ -93,6 +94,12 @@ struct Prof {
 //                   have been accepted, and rejected tests never change the scan's state, so the
 //                   sequence of accepted triangles -- tie rule included -- is unchanged.
 enum ScanMode { SCAN_LITERAL = 0, SCAN_FAST = 1, SCAN_TWO_PHASE = 2 };
+
+// Kinds of scene the path kernel is instantiated for: linear scan with the triangle and shading
+// records staged in LDS (scenes of at most LDS_TABLE_MAX primitives), linear scan from global
+// memory, LBVH.
+enum SceneKind { SCENE_LINEAR_LDS = 0, SCENE_LINEAR = 1, SCENE_BVH = 2 };
+constexpr int LDS_TABLE_MAX = 64;
 
 #ifndef MIPT_SCAN_MODE
 #define MIPT_SCAN_MODE 2
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
 #endif
 #define MIPT_PATHS_OCC __attribute__((amdgpu_waves_per_eu(MIPT_WAVES_PER_EU, MIPT_WAVES_PER_EU)))
 
-template <int RNG_MODE, bool STATS, bool LIST, bool BVH>
+template <int RNG_MODE, bool STATS, bool LIST, int KIND>
 __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a) {
   extern __shared__ uint32_t lds_stack[];  // [max_depth][BLOCK] tags, then sphere normals
   const int tid = threadIdx.x;
@@ -295,6 +302,22 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   uint32_t* tags = lds_stack;
   float* sph_n = reinterpret_cast<float*>(lds_stack + (size_t)P.max_depth * BLOCK);
   const bool fog = P.fog_sigma_t > 0.f;
+  constexpr bool BVH = KIND == SCENE_BVH;
+  // per-primitive records the shading reads by hit index: from LDS for small scenes
+  const TriRec* tri_tab = a.sc.tris;
+  const ShadeRec* shade_tab = a.sc.shade;
+  if (KIND == SCENE_LINEAR_LDS) {
+    uint32_t* tab = lds_stack + a.lds_table_off;
+    const int n_tri_dw = a.sc.n_tris * (int)(sizeof(TriRec) / 4);
+    const int n_shade_dw = (a.sc.n_tris + a.sc.n_spheres) * (int)(sizeof(ShadeRec) / 4);
+    const uint32_t* gt = reinterpret_cast<const uint32_t*>(a.sc.tris);
+    const uint32_t* gs = reinterpret_cast<const uint32_t*>(a.sc.shade);
+    for (int i = tid; i < n_shade_dw; i += BLOCK) tab[i] = gs[i];
+    for (int i = tid; i < n_tri_dw; i += BLOCK) tab[n_shade_dw + i] = gt[i];
+    __syncthreads();
+    shade_tab = reinterpret_cast<const ShadeRec*>(tab);
+    tri_tab = reinterpret_cast<const TriRec*>(tab + n_shade_dw);
+  }
   Prof prof{};
 #ifdef MIPT_PROFILE_SECTIONS
   __shared__ uint32_t prof_lds[PF_COUNT];
@@ -409,9 +432,9 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       if (h.idx < 0) {
         path_done = true;  // pathtracer.cpp:74-75: miss, colour stays 0
       } else {
-        const ShadeRec sh = a.sc.shade[h.idx];
+        const ShadeRec sh = shade_tab[h.idx];
         if (!sphere_hit) {
-          const TriRec T = a.sc.tris[h.idx];
+          const TriRec T = tri_tab[h.idx];
           pos.x = (T.v0x + h.by * T.e1x) + h.bz * T.e2x;  // intersections.cpp:29
           pos.y = (T.v0y + h.by * T.e1y) + h.bz * T.e2y;
           pos.z = (T.v0z + h.by * T.e1z) + h.bz * T.e2z;
@@ -438,6 +461,11 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
         // vector and ONE normalisation runs for all lanes after they rejoin.
         V4 nd = d;
         bool renorm = false, offset_origin = false;
+        // the fog's scattering and bounceDiffuse both end in sincos(phi) of a sampled direction:
+        // the branches prepare (phi, radius, axial component), one evaluation serves both
+        bool need_sc = false, scatter = false;
+        float sc_phi = 0.f, sc_r = 0.f, sc_y = 0.f;
+        V3 Nt = {sh.ntx, sh.nty, sh.ntz}, Nb = {sh.nbx, sh.nby, sh.nbz};
         const bool terminal = depth >= P.max_depth || rng_next<RNG_MODE>(rng) <= P.rr_prob;  // :80
         prof.mark(PF_HIT);
         if (terminal) {
@@ -452,6 +480,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           const V4 vecr = normalize4(v);
           const float r = sqrtf(dot4(v, v));
           const float den = (float)(((4.0 * 3.14159) * (double)r) * (double)r);  // light.cpp:22
+          const float tr = fog ? fog_expf(-(P.fog_sigma_t * r)) : 1.0f;  // transmittance to the light
           if (!medium) {
             // normalize(inter.normal) (light.cpp:20) is a per-triangle constant
             const V4 nn = sphere_hit ? normalize4(nrm) : V4{sh.nnx, sh.nny, sh.nnz, sh.nnw};
@@ -464,16 +493,12 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
               Lg = (a.light_col[1] * m) / den;
               Lb = (a.light_col[2] * m) / den;
             }
-            if (fog) {
-              const float tr = fog_expf(-(P.fog_sigma_t * r));
-              Lr = Lr * tr; Lg = Lg * tr; Lb = Lb * tr;
-            }
+            if (fog) { Lr = Lr * tr; Lg = Lg * tr; Lb = Lb * tr; }
             if (sh.material != MIPT_MAT_GLASS) {  // pathtracer.cpp:88-93
               Lr = (sh.r * Lr) * 1.0f; Lg = (sh.g * Lg) * 1.0f; Lb = (sh.b * Lb) * 1.0f;
             }
             o = add4(pos, scale4(vecr, 0.001f));  // light.cpp:25
           } else {
-            const float tr = fog_expf(-(P.fog_sigma_t * r));
             const float phase = 1.0f / (4.0f * 3.14159f);
             Lr = (((a.light_col[0] * phase) / den) * tr) * P.fog_albedo;
             Lg = (((a.light_col[1] * phase) / den) * tr) * P.fog_albedo;
@@ -488,13 +513,11 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           // isotropic scattering, weight = single-scattering albedo
           const float u1 = rng_next<RNG_MODE>(rng);
           const float u2 = rng_next<RNG_MODE>(rng);
-          const float z = 1.0f - 2.0f * u1;
-          const float s2 = 1.0f - z * z;
-          const float rxy = sqrtf(s2 < 0.f ? 0.f : s2);
-          const float phi = 6.28318530718f * u2;
-          float sn, cs;
-          sincosf_glibc(phi, sn, cs);
-          d = {rxy * cs, rxy * sn, z, 0.0f};
+          sc_y = 1.0f - 2.0f * u1;
+          const float s2 = 1.0f - sc_y * sc_y;
+          sc_r = sqrtf(s2 < 0.f ? 0.f : s2);
+          sc_phi = 6.28318530718f * u2;
+          need_sc = true; scatter = true;
           tags[sp * BLOCK + tid] = TAG_FOG;
           sp++; depth++;
           prof.mark(PF_SCATTER);
@@ -505,22 +528,13 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
             // bounceDiffuse (pathtracer.cpp:5-19), orthonormalSystem / diffuseHemisphere (utils.cpp:10-22)
             if (STATS) st[ST_DIFFUSE]++;
             // orthonormalSystem(normal) is a per-triangle constant, stored with the triangle
-            V3 Nt = {sh.ntx, sh.nty, sh.ntz}, Nb = {sh.nbx, sh.nby, sh.nbz};
             if (sphere_hit) orthonormal_system(nrm, Nt, Nb);
             // g++ evaluates the two argument draws right to left: first draw -> b, second -> a
             const float ub = rng_next<RNG_MODE>(rng);
-            const float ua = rng_next<RNG_MODE>(rng);
-            const float rr = sqrtf(1.0f - ua * ua);
-            const float phi = (float)((2 * 3.14) * (double)ub);
-            float sn, cs;
-            sincosf_glibc(phi, sn, cs);
-            const float sx = cs * rr, sy = ua, sz = sn * rr;
-            V4 rd;
-            rd.x = (sx * Nb.x + sy * nrm.x) + sz * Nt.x;
-            rd.y = (sx * Nb.y + sy * nrm.y) + sz * Nt.y;
-            rd.z = (sx * Nb.z + sy * nrm.z) + sz * Nt.z;
-            rd.w = 1.0f;
-            nd = rd; renorm = true; offset_origin = true;  // origin += dir * 0.001 after normalising
+            sc_y = rng_next<RNG_MODE>(rng);
+            sc_r = sqrtf(1.0f - sc_y * sc_y);
+            sc_phi = (float)((2 * 3.14) * (double)ub);
+            need_sc = true;
             tags[sp * BLOCK + tid] = (uint32_t)h.idx;
             if (sphere_hit) {
               float* q = sph_n + ((size_t)sp * BLOCK + tid) * 4;
@@ -568,6 +582,20 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
             path_done = true;  // no branch of pathtracer.cpp:103-110 taken: colour stays 0
           }
         }
+        if (need_sc) {
+          float sn, cs;
+          sincosf_glibc(sc_phi, sn, cs);
+          const float sx = cs * sc_r, sz = sn * sc_r;
+          if (scatter) {
+            d = {sx, sz, sc_y, 0.0f};
+          } else {  // utils.cpp:20-22 and pathtracer.cpp:9-13
+            nd.x = (sx * Nb.x + sc_y * nrm.x) + sz * Nt.x;
+            nd.y = (sx * Nb.y + sc_y * nrm.y) + sz * Nt.y;
+            nd.z = (sx * Nb.z + sc_y * nrm.z) + sz * Nt.z;
+            nd.w = 1.0f;
+            renorm = true; offset_origin = true;  // origin += dir * 0.001 after normalising
+          }
+        }
         if (renorm) {
           d = normalize4(nd);
           if (offset_origin) o = add4(o, scale4(d, 0.001f));  // pathtracer.cpp:14
@@ -586,7 +614,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           } else if (tag == TAG_FOG) {
             cr = cr * P.fog_albedo; cg = cg * P.fog_albedo; cb = cb * P.fog_albedo;
           } else {  // pathtracer.cpp:18, with the direction of the last segment
-            const ShadeRec sv = a.sc.shade[tag];
+            const ShadeRec sv = shade_tab[tag];
             V4 N = {sv.nx, sv.ny, sv.nz, sv.nw};
             if ((int)tag >= a.sc.n_tris) {
               const float* q = sph_n + ((size_t)k * BLOCK + tid) * 4;
@@ -663,6 +691,20 @@ __global__ __launch_bounds__(BLOCK) void k_selfcheck_rcp(unsigned long long* out
   }
   if (bad) atomicAdd(out + 0, (unsigned long long)bad);
   atomicMax(out + 1, (unsigned long long)worst);
+}
+
+// out[6]: floats in [0, 2 pi] for which the fused-arithmetic sincos differs from the plain one
+__global__ __launch_bounds__(BLOCK) void k_selfcheck_sincos(unsigned long long* out) {
+  const uint32_t stride = gridDim.x * BLOCK;
+  uint32_t bad = 0;
+  for (uint32_t bits = blockIdx.x * BLOCK + threadIdx.x; bits <= 0x40C90FDBu; bits += stride) {
+    const float y = __uint_as_float(bits);
+    float s0, c0, s1, c1;
+    sincosf_glibc_impl<false>(y, s0, c0);
+    sincosf_glibc_impl<true>(y, s1, c1);
+    bad += (__float_as_uint(s0) != __float_as_uint(s1) || __float_as_uint(c0) != __float_as_uint(c1)) ? 1u : 0u;
+  }
+  if (bad) atomicAdd(out + 6, (unsigned long long)bad);
 }
 
 template <bool BVH>

@@ -234,8 +234,9 @@ int mipt_get_stats(MiptScene* scene, MiptStats* out);
  * For a scene with an LBVH, (2) compares the tree traversal with the literal linear scan.
  * out[0] = reciprocal mismatches, out[1] = worst error of the hardware reciprocal estimate in
  * 2^-10 ulp, out[2] / out[3] = rays whose closest-hit / any-hit result differs, out[4] = rays
- * re-run through the exhaustive tree traversal, out[5] = traversal overflows, out[6..7] = 0.
- * All of out[0], out[2], out[3], out[5] must be 0. */
+ * re-run through the exhaustive tree traversal, out[5] = traversal overflows, out[6] = floats in
+ * [0, 2 pi] whose fused-arithmetic sine / cosine differs from the plain evaluation, out[7] = 0.
+ * All of out[0], out[2], out[3], out[5], out[6] must be 0. */
 int mipt_debug_selfcheck(MiptScene* scene, uint64_t n_rays, uint32_t seed, uint64_t out[8]);
 
 /* The (seed, pixel, sample) -> 32-bit key shared by both per-path RNG modes.

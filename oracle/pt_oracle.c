@@ -426,11 +426,51 @@ typedef struct {
   OrCounters* cn;
 } OrCtx;
 
-/* The fog's transcendental functions: evaluated in double and rounded once to float, so that
- * a host libm and a device libm give the same float (both are far more accurate than the final
- * rounding). The fog has no reference code; this choice is part of its definition here. */
-static float fog_logf(float x) { return (float)log((double)x); }
-static float fog_expf(float x) { return (float)exp((double)x); }
+/* The fog's transcendental functions: fixed sequences of binary32 operations with explicit
+ * fused multiply-adds (fmaf is exact by definition), so that any host and the device agree bit
+ * for bit. Cephes-style argument reduction and polynomials, ~1 ulp. The fog has no reference
+ * code; these sequences are part of its definition here. */
+static float fog_bits_to_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+float or_fog_expf(float x) {
+  if (!(x > -87.0f)) return 0.0f;
+  if (x > 88.0f) x = 88.0f;
+  const float k = rintf(x * 1.44269504088896341f);
+  float r = fmaf(k, -0.693359375f, x);
+  r = fmaf(k, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  const float y = fmaf(p, r * r, r) + 1.0f;
+  return y * fog_bits_to_float((uint32_t)((int32_t)k + 127) << 23);
+}
+float or_fog_logf(float x) { /* x > 0 and normal */
+  if (!(x > 0.0f)) return -INFINITY;
+  uint32_t ix;
+  memcpy(&ix, &x, 4);
+  int32_t e = (int32_t)(ix >> 23) - 126;
+  float m = fog_bits_to_float((ix & 0x007FFFFFu) | 0x3F000000u);
+  if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+  const float z = m * m;
+  float p = 7.0376836292e-2f;
+  p = fmaf(p, m, -1.1514610310e-1f);
+  p = fmaf(p, m, 1.1676998740e-1f);
+  p = fmaf(p, m, -1.2420140846e-1f);
+  p = fmaf(p, m, 1.4249322787e-1f);
+  p = fmaf(p, m, -1.6668057665e-1f);
+  p = fmaf(p, m, 2.0000714765e-1f);
+  p = fmaf(p, m, -2.4999993993e-1f);
+  p = fmaf(p, m, 3.3333331174e-1f);
+  float y = (p * m) * z;
+  const float fe = (float)e;
+  y = fmaf(fe, -2.12194440e-4f, y);
+  y = fmaf(z, -0.5f, y);
+  return fmaf(fe, 0.693359375f, m + y);
+}
+#define fog_expf or_fog_expf
+#define fog_logf or_fog_logf
 
 /* directLight (light.cpp:13-31). fog: transmittance along the light segment. */
 static void direct_light(const OrCtx* cx, const float pos[4], const float normal[4],

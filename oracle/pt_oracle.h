@@ -97,6 +97,10 @@ float or_length4(const float v[4]);
 void or_mat4_mul(const float a[16], const float b[16], float out[16]);
 void or_mat4_mul_vec4(const float m[16], const float v[4], float out[4]);
 
+/* the fog's exp / log (fixed binary32 operation sequences, see pt_oracle.c) */
+float or_fog_expf(float x);
+float or_fog_logf(float x);
+
 #ifdef __cplusplus
 }
 #endif

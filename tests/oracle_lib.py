@@ -58,6 +58,10 @@ def oracle(fast=False):
                                          vp, C.c_int, P(abi.MiptStats)]
     lib.or_resolve_argb.argtypes = [vp, C.c_int, C.c_int, C.c_uint32, vp]
     lib.or_resolve_argb.restype = None
+    lib.or_fog_expf.argtypes = [C.c_float]
+    lib.or_fog_expf.restype = C.c_float
+    lib.or_fog_logf.argtypes = [C.c_float]
+    lib.or_fog_logf.restype = C.c_float
     lib.or_det3.argtypes = [vp, vp, vp]
     lib.or_det3.restype = C.c_float
     lib.or_inverse3_mul.argtypes = [vp] * 5

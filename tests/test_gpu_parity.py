@@ -63,6 +63,7 @@ def test_fast_scan_equals_literal_scan_at_scale(api, O, scene):
     tris = O.load_test_model(SCENES[scene][0])
     sc = api.Scene(tris)
     rcp_bad, rcp_err_ulp, closest_bad, any_bad = sc.selfcheck(1 << 30, seed=123)
+    assert sc.last_selfcheck_sincos == 0
     sc.close()
     assert rcp_bad == 0
     assert rcp_err_ulp <= 1.0, rcp_err_ulp   # the gate's band of 2^-20 assumes an estimate good to ~1 ulp

@@ -81,3 +81,24 @@ def test_bary_bound_constant():
     # (double)(float sum) <= 1.001 is the same predicate as sum <= 0x3F8020C4 (largest float below 1.001)
     f = np.array([0x3F8020C4, 0x3F8020C5], dtype=np.uint32).view(np.float32)
     assert float(f[0]) <= 1.001 < float(f[1])
+
+
+def test_fog_exp_log_are_accurate(O):
+    # the fog's exp / log are fixed float operation sequences (so host and device agree bit for
+    # bit); they must still BE exp and log: within 2 ulp of the correctly rounded values
+    o = O.oracle()
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([-rng.uniform(0, 30, 20000), -np.logspace(-8, 1.9, 2000), [0.0, -86.9, -87.5, -1e-30]])
+    for x in xs.astype(np.float32):
+        got, want = np.float32(o.or_fog_expf(float(x))), np.exp(np.float64(x))
+        if x <= -87.0:
+            assert got == 0.0
+        else:
+            assert abs(np.float64(got) - want) <= 2 * np.spacing(np.float32(want)), (x, got, want)
+    us = np.concatenate([rng.uniform(0, 1, 20000), 1 - np.logspace(-7.2, -0.01, 2000), [1.0, 2.0 ** -24, 0.5, 0.70710677, 0.7071068]])
+    for x in us.astype(np.float32):
+        if x <= 0:
+            continue
+        got, want = np.float32(o.or_fog_logf(float(x))), np.log(np.float64(x))
+        tol = 2 * abs(np.spacing(np.float32(want))) if want != 0 else 1e-45
+        assert abs(np.float64(got) - want) <= tol, (x, got, want)
