@@ -171,6 +171,10 @@ class Scene:
         has = self._lib.mipt_scene_has_bvh(self._h, C.byref(n), C.byref(ms))
         return bool(has), int(n.value), float(ms.value)
 
+    def pair_units(self):
+        """pairs of coplanar triangles the linear scan's candidate filter merged"""
+        return int(self._lib.mipt_scene_pair_units(self._h))
+
     def stats(self):
         s = abi.MiptStats()
         _check(self._lib.mipt_get_stats(self._h, C.byref(s)))

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -48,6 +49,8 @@ struct MiptScene {
   int device = 0;
   DeviceScene d{};
   TriRec* d_tris = nullptr;
+  ScanUnit* d_units = nullptr;
+  uint32_t n_pair_units = 0;
   ShadeRec* d_shade = nullptr;
   SphereRec* d_spheres = nullptr;
   unsigned long long* d_stats = nullptr;
@@ -66,6 +69,7 @@ static void scene_free(MiptScene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   if (s->d_tris) (void)hipFree(s->d_tris);
+  if (s->d_units) (void)hipFree(s->d_units);
   if (s->d_shade) (void)hipFree(s->d_shade);
   if (s->d_spheres) (void)hipFree(s->d_spheres);
   if (s->d_stats) (void)hipFree(s->d_stats);
@@ -146,6 +150,111 @@ static int build_bvh(MiptScene* s, int n) {
   s->bvh_build_ms = ms;
   s->d.bvh = s->d_bvh;
   return MIPT_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// scan units of the linear scan's candidate filter (ScanUnit in mipt_device.hpp)
+
+static inline bool same_vertex(const float* a, const float* b) { return memcmp(a, b, 12) == 0; }
+
+// Can triangles A, B (consecutive indices) be filtered as one unit? They must share an edge
+// bitwise, lie in one plane to 10^-6 of their size, and B's far vertex q must sit beyond the shared
+// edge with (qu, qv) in a range that keeps the error amplification of unit_candidates <= 9.
+static bool make_pair_unit(const MiptTriangle& A, const MiptTriangle& B, ScanUnit& u) {
+  const float* av[3] = {A.v0, A.v1, A.v2};
+  const float* bv[3] = {B.v0, B.v1, B.v2};
+  int a_of_b[3] = {-1, -1, -1}, n_shared = 0;
+  bool a_used[3] = {false, false, false};
+  for (int j = 0; j < 3; ++j)
+    for (int i = 0; i < 3; ++i)
+      if (!a_used[i] && a_of_b[j] < 0 && same_vertex(av[i], bv[j])) { a_of_b[j] = i; a_used[i] = true; ++n_shared; }
+  if (n_shared != 2) return false;
+  int ir = 0, jq = 0;
+  for (int i = 0; i < 3; ++i) if (!a_used[i]) ir = i;
+  for (int j = 0; j < 3; ++j) if (a_of_b[j] < 0) jq = j;
+  const float* r = av[ir];
+  const float* s1 = av[(ir + 1) % 3];
+  const float* s2 = av[(ir + 2) % 3];
+  const float* q = bv[jq];
+  volatile float f1[3], f2[3];
+  double F1[3], F2[3], Q[3];
+  float emax = 0.f;
+  for (int k = 0; k < 3; ++k) {
+    f1[k] = s1[k] - r[k]; f2[k] = s2[k] - r[k];
+    F1[k] = f1[k]; F2[k] = f2[k]; Q[k] = (double)q[k] - (double)r[k];
+    // every edge of either triangle: the frame's, the shared one, and the two to q
+    const float e[5] = {f1[k], f2[k], s2[k] - s1[k], q[k] - s1[k], q[k] - s2[k]};
+    for (float x : e) emax = std::fmax(emax, std::fabs(x));
+  }
+  float vmax = 0.f;
+  for (int k = 0; k < 3; ++k) vmax = std::fmax(vmax, std::fmax(std::fabs(r[k]), std::fabs(q[k])));
+  if (!(emax >= 9.094947e-13f && emax <= 1.0995116e12f && vmax <= 1.0995116e12f)) return false;
+  const double N[3] = {F1[1] * F2[2] - F1[2] * F2[1], F1[2] * F2[0] - F1[0] * F2[2], F1[0] * F2[1] - F1[1] * F2[0]};
+  const double nn = N[0] * N[0] + N[1] * N[1] + N[2] * N[2];
+  // the frame must be well shaped: area at least 10^-3 of emax^2
+  if (!(nn > 1e-6 * (double)emax * emax * (double)emax * emax)) return false;
+  const double QxF2[3] = {Q[1] * F2[2] - Q[2] * F2[1], Q[2] * F2[0] - Q[0] * F2[2], Q[0] * F2[1] - Q[1] * F2[0]};
+  const double F1xQ[3] = {F1[1] * Q[2] - F1[2] * Q[1], F1[2] * Q[0] - F1[0] * Q[2], F1[0] * Q[1] - F1[1] * Q[0]};
+  const double qu = (QxF2[0] * N[0] + QxF2[1] * N[1] + QxF2[2] * N[2]) / nn;
+  const double qv = (F1xQ[0] * N[0] + F1xQ[1] * N[1] + F1xQ[2] * N[2]) / nn;
+  const double h = (Q[0] * N[0] + Q[1] * N[1] + Q[2] * N[2]) / std::sqrt(nn);  // distance of q from the plane
+  if (!(std::fabs(h) <= 1e-6 * emax)) return false;
+  const double area_ratio = qu + qv - 1.0;  // area(B) / area(A)
+  if (!(area_ratio >= 0.5 && std::fabs(qu) <= 2.0 && std::fabs(qv) <= 2.0)) return false;
+  memset(&u, 0, sizeof u);
+  u.v0x = r[0]; u.v0y = r[1]; u.v0z = r[2];
+  u.e1x = f1[0]; u.e1y = f1[1]; u.e1z = f1[2];
+  u.e2x = f2[0]; u.e2y = f2[1]; u.e2z = f2[2];
+  // tri_candidate's 2^-12 E1 E2 and 2^-17 max(E1, E2) with E = emax; x2 for the frame not being the
+  // reference's labelling, x2 (kB) for S = 2 max(|s|, emax), x4 (kA) for the coplanarity tolerance,
+  // / area_ratio where the second triangle's own determinant is the smaller one
+  u.kA = (float)(0.000244140625 * 8.0 * (double)emax * emax / std::fmin(1.0, area_ratio));
+  u.kB = 7.62939453125e-06f * 4.0f * emax;
+  u.emax = emax;
+  u.qc = (float)(1.0 / area_ratio); u.qu = (float)qu; u.qv = (float)qv;
+  return true;
+}
+
+static void make_single_unit(const TriRec& t, ScanUnit& u) {
+  memset(&u, 0, sizeof u);
+  u.v0x = t.v0x; u.v0y = t.v0y; u.v0z = t.v0z;
+  u.e1x = t.e1x; u.e1y = t.e1y; u.e1z = t.e1z;
+  u.e2x = t.e2x; u.e2y = t.e2y; u.e2z = t.e2z;
+  u.kA = t.kA; u.kB = t.kB;
+}
+
+// per chunk of 32 triangles: pairs (greedy over consecutive indices) first, then singles
+static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>& tr, size_t n_tris,
+                             std::vector<ScanUnit>& units, uint32_t& n_pair_units) {
+  const size_t n_chunks = (n_tris + 31) / 32;
+  units.assign(n_chunks * 32 + 1, ScanUnit{});
+  n_pair_units = 0;
+  const char* no_pairs = getenv("MIPT_NO_PAIRS");  // developer switch: every triangle its own unit
+  const bool pairing = !(no_pairs && no_pairs[0] == '1');
+  for (size_t c = 0; c < n_chunks; ++c) {
+    const size_t lo = c * 32, hi = std::min(n_tris, lo + 32);
+    std::vector<ScanUnit> pairs, singles;
+    for (size_t i = lo; i < hi;) {
+      ScanUnit u;
+      if (pairing && i + 1 < hi && std::isfinite(tr[i].kA) && std::isfinite(tr[i + 1].kA) &&
+          make_pair_unit(tris[i], tris[i + 1], u)) {
+        u.meta = (uint32_t)(i - lo) | ((uint32_t)(i + 1 - lo) << 5);
+        pairs.push_back(u);
+        i += 2;
+      } else {
+        make_single_unit(tr[i], u);
+        u.meta = (uint32_t)(i - lo);
+        singles.push_back(u);
+        i += 1;
+      }
+    }
+    size_t k = lo;
+    for (const ScanUnit& u : pairs) units[k++] = u;
+    for (const ScanUnit& u : singles) units[k++] = u;
+    units[lo].meta |= ((uint32_t)pairs.size() << 16) | ((uint32_t)(pairs.size() + singles.size()) << 24);
+    n_pair_units += (uint32_t)pairs.size();
+  }
 }
 
 static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
@@ -231,6 +340,11 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
   s->d.scale = scale;
   const char* no_bvh = getenv("MIPT_NO_BVH");  // developer switch: always scan linearly
   if (n_tris >= MIPT_BVH_MIN_TRIS && !(no_bvh && no_bvh[0] == '1')) return build_bvh(s, (int)n_tris);
+  std::vector<ScanUnit> units;
+  build_scan_units(tris, tr, n_tris, units, s->n_pair_units);
+  HIP_TRY(hipMalloc(&s->d_units, units.size() * sizeof(ScanUnit)));
+  HIP_TRY(hipMemcpy(s->d_units, units.data(), units.size() * sizeof(ScanUnit), hipMemcpyHostToDevice));
+  s->d.units = s->d_units;
   return MIPT_OK;
 }
 
@@ -272,6 +386,8 @@ extern "C" int mipt_scene_has_bvh(MiptScene* s, uint64_t* n_nodes, double* build
   if (build_ms) *build_ms = s->bvh_build_ms;
   return 1;
 }
+
+extern "C" int mipt_scene_pair_units(MiptScene* s) { return s ? (int)s->n_pair_units : 0; }
 
 extern "C" int mipt_closest_hit_dev(MiptScene* s, const float* d_origin4, const float* d_dir4, size_t n_rays,
                                     int32_t* d_tri_idx, float* d_t, float* d_position4, void* stream) {

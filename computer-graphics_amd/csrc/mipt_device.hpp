@@ -57,10 +57,32 @@ struct __attribute__((aligned(16))) SphereRec {
   uint32_t material, pad0, pad1, pad2;
 };
 
+// ScanUnit: what phase 1 of the linear scan (the candidate filter) reads, one 64-byte record per
+// UNIT: a single triangle, or two triangles with consecutive indices that share an edge and lie in
+// one plane (the two halves of a wall, of a box face). A pair is filtered with ONE evaluation of
+// the ray / plane system in the frame (r; f1, f2): r = the first triangle's vertex off the shared
+// edge, f1, f2 = the edges from r to the shared vertices. In that frame the first triangle is
+// u, v >= 0, u + v <= 1 and the second has barycentrics lq = (u + v - 1) qc, u - qu lq, v - qv lq,
+// (qu, qv) = its far vertex, qc = 1 / (qu + qv - 1). Units are stored per chunk of 32 triangles
+// (records [32 c, 32 c + n_units), pairs first); meta of a chunk's first record carries the
+// counts. The filter frame need not be the reference's labelling of the vertices: the filter is
+// only ever asked "can the reference's test of this triangle possibly accept".
+struct __attribute__((aligned(64))) ScanUnit {
+  float v0x, v0y, v0z;
+  float e1x, e1y, e1z;
+  float e2x, e2y, e2z;
+  float kA, kB;      // error-bound factors as in TriRec, widened for pairs (see build_scan_units)
+  float emax;        // pairs: largest |edge|oo of the two triangles (0 for single triangles)
+  float qc, qu, qv;  // pairs: the second triangle in the frame of the first
+  uint32_t meta;     // bits 0-4 / 5-9: mask bit of the first / second triangle; 16-23: pairs in
+                     // this chunk; 24-31: units in this chunk (first record of a chunk only)
+};
+
 struct BvhNode;
 
 struct DeviceScene {
   const BvhNode* bvh;  // LBVH over the triangles, or null: linear scan
+  const ScanUnit* units;  // phase-1 records of the linear scan (null with an LBVH)
   const TriRec* tris;
   const ShadeRec* shade;  // n_tris triangle records followed by n_spheres sphere records
   const SphereRec* spheres;
@@ -370,6 +392,53 @@ __device__ __forceinline__ bool tri_candidate(TP T, float ox, float oy, float oz
   const float dt = (S * T->kT) * ainv + 1e-30f;
   const bool outside = (u < -delta) | (v < -delta) | (u + v > 1.001f + 2.0f * delta) | (t < -dt);
   return !(well & outside);
+}
+
+// The candidate filter over a scan unit: tri_candidate's system solved once for a pair. Sets the
+// units' mask bits in `mask` for every triangle of the unit the reference could accept.
+// Error model of a pair: the frame's edges are not the reference's e1, e2, and the second
+// triangle's own reference determinants are those of the frame times its area ratio; every
+// |edge|oo involved is <= emax and every |o - vertex|oo <= |s|oo + emax <= 2 max(|s|oo, emax), so
+// the bounds of tri_candidate hold with E1 = E2 = emax and S = 2 max(|s|oo, emax) (the factors
+// are folded into kA, kB on the host). The second triangle's barycentrics amplify an error in
+// (u, v) by at most 1 + 2 qc max(|qu|, |qv|) <= 9 (pairs beyond that are not merged), and the
+// merge tolerance on coplanarity moves them by < 0.01 for a ray that passes `well`.
+template <bool PAIR, typename UP>
+__device__ __forceinline__ void unit_candidates(UP U, float ox, float oy, float oz, float dx, float dy,
+                                                float dz, float Dm, uint32_t& mask) {
+#pragma clang fp contract(fast)
+  const float sx = ox - U->v0x, sy = oy - U->v0y, sz = oz - U->v0z;
+  const float e1x = U->e1x, e1y = U->e1y, e1z = U->e1z;
+  const float e2x = U->e2x, e2y = U->e2y, e2z = U->e2z;
+  const float pvx = dy * e2z - dz * e2y, pvy = dz * e2x - dx * e2z, pvz = dx * e2y - dy * e2x;
+  const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+  const float un = sx * pvx + sy * pvy + sz * pvz;
+  const float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;
+  const float vn = dx * qx + dy * qy + dz * qz;
+  const float tn = e2x * qx + e2y * qy + e2z * qz;
+  float S = fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz));
+  if (PAIR) S = fmaxf(S, U->emax);
+  const float kA = U->kA;
+  const bool well = fabsf(det) >= Dm * kA + 1e-35f;
+  const float inv = __builtin_amdgcn_rcpf(det);
+  const float u = un * inv, v = vn * inv, t = tn * inv;
+  const float w1 = S * fabsf(inv);
+  const float drel = (w1 * Dm) * U->kB;
+  const float delta = drel + (PAIR ? 0.022f : 0.02f);
+  // kT of tri_candidate is kA 2^-5; a pair's S carries a factor 2 that is folded in here
+  const float dt = (w1 * kA) * (PAIR ? 0.0625f : 0.03125f) + 1e-30f;
+  const bool behind = t < -dt;
+  const float uv = u + v;
+  const bool outA = (u < -delta) | (v < -delta) | (uv > 1.001f + 2.0f * delta) | behind;
+  const uint32_t meta = U->meta;
+  if (!(well & outA)) mask |= 1u << (meta & 31u);
+  if (PAIR) {
+    const float lq = (uv - 1.0f) * U->qc;
+    const float l1 = u - U->qu * lq, l2 = v - U->qv * lq;
+    const float dB = drel * 9.0f + 0.06f;
+    const bool outB = (lq < -dB) | (l1 < -dB) | (l2 < -dB) | behind;
+    if (!(well & outB)) mask |= 1u << ((meta >> 5) & 31u);
+  }
 }
 
 // One triangle of the scan. FAST = false is the literal reference arithmetic. FAST = true decides

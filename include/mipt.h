@@ -171,6 +171,10 @@ int mipt_scene_create(const MiptTriangle* tris, size_t n_tris,
  * and the build time in *build_ms (nullable). */
 #define MIPT_BVH_MIN_TRIS 256
 int mipt_scene_has_bvh(MiptScene* scene, uint64_t* n_nodes, double* build_ms);
+/* Linear-scan scenes: how many pairs of consecutive coplanar triangles sharing an edge (the two
+ * halves of a wall or box face, TestModelH.h:87-160) the candidate filter treats as one unit.
+ * Purely an optimisation of the filter; every candidate still goes through the reference's test. */
+int mipt_scene_pair_units(MiptScene* scene);
 void mipt_scene_destroy(MiptScene* scene);
 
 /* Batch closestIntersection (intersections.cpp:6-55). Host pointers.

@@ -267,3 +267,58 @@ def test_fog_matches_oracle_statistically(api, O, pkg):
     orgb, _ = O.trace_paths(tris, None, cam, light, p2, px, py, smp)
     frac_paths = float(np.all(bits(rgb) == bits(orgb), axis=1).mean())
     assert frac_paths > 0.999, frac_paths
+
+
+def quad_scene(O, dtype, n_quads, seed):
+    """Random planar quads split into two triangles with every vertex labelling, next to each other
+    in index order: parallelograms, general convex quads, thin ones, at scales 1e-3 .. 1; plus
+    near-pairs that must NOT merge (bent quads, triangles sharing only a vertex)."""
+    import bigscenes
+    rng = np.random.default_rng(seed)
+    v0s, v1s, v2s = [], [], []
+    for k in range(n_quads):
+        c = rng.uniform(-0.8, 0.8, 3)
+        size = 10 ** rng.uniform(-3, 0)
+        a = rng.normal(size=3); a /= np.linalg.norm(a)
+        b = rng.normal(size=3); b -= a * (a @ b); b /= np.linalg.norm(b)
+        aspect = 10 ** rng.uniform(-1.5, 0)
+        P = [c, c + a * size, c + a * size + b * size * aspect, c + b * size * aspect]   # parallelogram
+        kind = k % 4
+        if kind == 1:    # general convex quad: move one corner in the plane
+            P[2] = P[2] + (a * rng.uniform(-0.3, 0.6) + b * aspect * rng.uniform(-0.3, 0.6)) * size
+        elif kind == 2:  # bent: one corner out of the plane (must not merge, or merge harmlessly)
+            P[2] = P[2] + np.cross(a, b) * size * 10 ** rng.uniform(-7, -1)
+        P = [np.float32(p) for p in P]
+        t1 = [P[0], P[1], P[2]]
+        t2 = [P[0], P[2], P[3]] if kind != 3 else [P[0] + np.float32(1e-3), P[2], P[3]]  # kind 3: only one shared vertex
+        r1, r2 = rng.permutation(3), rng.permutation(3)
+        for t, r in ((t1, r1), (t2, r2)):
+            v0s.append(t[r[0]]); v1s.append(t[r[1]]); v2s.append(t[r[2]])
+    n = len(v0s)
+    color = rng.uniform(0.2, 0.9, (n, 3)).astype(np.float32)
+    return bigscenes._finish(dtype, np.array(v0s), np.array(v1s), np.array(v2s), color, np.zeros(n, dtype=np.uint32))
+
+
+def test_cornell_walls_are_filtered_as_pairs(api, O):
+    # GlassCube: 5 walls, 5 faces of the block, the mirror = 11 pairs of 22 triangles
+    sc = api.Scene(O.load_test_model(2))
+    assert sc.pair_units() == 11
+    sc.close()
+    sc = api.Scene(O.load_test_model(0))
+    assert sc.pair_units() >= 13   # 5 walls + 4 side faces of each block (their tops are no parallelograms)
+    sc.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_pair_filter_equals_literal_scan_on_random_quads(api, O, pkg, seed):
+    tris = quad_scene(O, pkg.abi.TRIANGLE_DTYPE, 60, seed)   # 120 triangles: linear scan, 4 chunks
+    sc = api.Scene(tris)
+    assert not sc.bvh_info()[0]
+    assert sc.pair_units() >= 20
+    _, _, closest_bad, any_bad = sc.selfcheck(1 << 26, seed=seed)
+    assert (closest_bad, any_bad) == (0, 0)
+    o, d = raygen.surface_rays(tris, 1 << 14, seed=seed)
+    idx, t, pos = sc.closest_hit(o, d)
+    sc.close()
+    oidx, ot, opos = O.closest_hit(tris, None, o, d)
+    assert np.array_equal(idx, oidx)
