@@ -209,7 +209,7 @@ static bool make_pair_unit(const MiptTriangle& A, const MiptTriangle& B, ScanUni
   // tri_candidate's 2^-12 E1 E2 and 2^-17 max(E1, E2) with E = emax; x2 for the frame not being the
   // reference's labelling, x2 (kB) for S = 2 max(|s|, emax), x4 (kA) for the coplanarity tolerance,
   // / area_ratio where the second triangle's own determinant is the smaller one
-  u.kA = (float)(0.000244140625 * 8.0 * (double)emax * emax / std::fmin(1.0, area_ratio));
+  u.kA = (float)(0.000244140625 * 8.0 * FILTER_TIGHT * (double)emax * emax / std::fmin(1.0, area_ratio));
   u.kB = 7.62939453125e-06f * 4.0f * emax;
   u.emax = emax;
   u.qc = (float)(1.0 / area_ratio); u.qu = (float)qu; u.qv = (float)qv;
@@ -292,7 +292,7 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
     const float V0 = std::fmax(std::fmax(std::fabs(r.v0x), std::fabs(r.v0y)), std::fabs(r.v0z));
     const bool sane = E1 >= 9.094947e-13f && E1 <= 1.0995116e12f && E2 >= 9.094947e-13f && E2 <= 1.0995116e12f &&
                       V0 <= 1.0995116e12f;  // [2^-40, 2^40]; NaN fails
-    r.kA = sane ? 0.000244140625f * (E1 * E2) : INFINITY;      // 2^-12
+    r.kA = sane ? (0.000244140625f * FILTER_TIGHT) * (E1 * E2) : INFINITY;  // 2^-12
     r.kB = sane ? 7.62939453125e-06f * std::fmax(E1, E2) : 0.f;  // 2^-17
     r.kT = sane ? 7.62939453125e-06f * (E1 * E2) : 0.f;
     ShadeRec& q = sh[i];
@@ -701,13 +701,15 @@ extern "C" int mipt_get_stats(MiptScene* s, MiptStats* out) {
   {
     unsigned long long pf[PF_COUNT];
     HIP_TRY(hipMemcpy(pf, s->d_stats + ST_COUNT, sizeof pf, hipMemcpyDeviceToHost));
-    static const char* names[PF_COUNT] = {"queue", "raygen", "phase1", "phase2", "hit", "terminal", "scatter",
+    static const char* names[PF_N_QUERIES] = {"queue", "raygen", "phase1", "phase2", "hit", "terminal", "scatter",
                                           "diffuse", "mirror", "glass", "renorm", "unwind"};
     double tot = 0;
-    for (int k = 0; k < PF_COUNT; ++k) tot += (double)pf[k];
+    for (int k = 0; k < PF_N_QUERIES; ++k) tot += (double)pf[k];
     fprintf(stderr, "[mipt sections, %% of wave time]");
-    for (int k = 0; k < PF_COUNT; ++k) fprintf(stderr, " %s %.1f", names[k], 100.0 * (double)pf[k] / (tot > 0 ? tot : 1));
-    fprintf(stderr, " (total %.3g ticks)\n", tot);
+    for (int k = 0; k < PF_N_QUERIES; ++k) fprintf(stderr, " %s %.1f", names[k], 100.0 * (double)pf[k] / (tot > 0 ? tot : 1));
+    fprintf(stderr, " (total %.3g ticks); candidates per query %.2f, phase-2 rounds per wave query %.2f\n", tot,
+            (double)pf[PF_N_CANDS] / (double)(pf[PF_N_QUERIES] ? pf[PF_N_QUERIES] : 1),
+            64.0 * (double)pf[PF_N_ROUNDS] / (double)(pf[PF_N_QUERIES] ? pf[PF_N_QUERIES] : 1));
   }
 #endif
   if (s->stats_valid) {

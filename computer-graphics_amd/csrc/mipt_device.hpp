@@ -356,6 +356,13 @@ __device__ __forceinline__ float rcp_exact(float b, float r0) {
   return 1.0f / b;
 }
 
+// MIPT_FILTER_TIGHT = k: the filters demand a determinant k times further from zero before they
+// trust their own (u, v, t) and in exchange shrink their constant margins by k.
+#ifndef MIPT_FILTER_TIGHT
+#define MIPT_FILTER_TIGHT 1
+#endif
+constexpr float FILTER_TIGHT = (float)MIPT_FILTER_TIGHT;
+
 // Candidate filter of the two-phase scan: returns false only when the reference's test of this
 // triangle provably cannot accept, whatever the running minimum is. It evaluates the same
 // linear system by Moeller-Trumbore in fused arithmetic (u, v, t ~ x.y, x.z, t of the reference)
@@ -388,7 +395,7 @@ __device__ __forceinline__ bool tri_candidate(TP T, float ox, float oy, float oz
   const float inv = __builtin_amdgcn_rcpf(det);
   const float ainv = fabsf(inv);
   const float u = un * inv, v = vn * inv, t = tn * inv;
-  const float delta = ((S * Dm) * T->kB) * ainv + 0.02f;
+  const float delta = ((S * Dm) * T->kB) * ainv + 0.02f / FILTER_TIGHT;
   const float dt = (S * T->kT) * ainv + 1e-30f;
   const bool outside = (u < -delta) | (v < -delta) | (u + v > 1.001f + 2.0f * delta) | (t < -dt);
   return !(well & outside);
@@ -424,7 +431,7 @@ __device__ __forceinline__ void unit_candidates(UP U, float ox, float oy, float 
   const float u = un * inv, v = vn * inv, t = tn * inv;
   const float w1 = S * fabsf(inv);
   const float drel = (w1 * Dm) * U->kB;
-  const float delta = drel + (PAIR ? 0.022f : 0.02f);
+  const float delta = drel + (PAIR ? 0.02f / FILTER_TIGHT + 0.002f : 0.02f / FILTER_TIGHT);
   // kT of tri_candidate is kA 2^-5; a pair's S carries a factor 2 that is folded in here
   const float dt = (w1 * kA) * (PAIR ? 0.0625f : 0.03125f) + 1e-30f;
   const bool behind = t < -dt;
@@ -435,7 +442,7 @@ __device__ __forceinline__ void unit_candidates(UP U, float ox, float oy, float 
   if (PAIR) {
     const float lq = (uv - 1.0f) * U->qc;
     const float l1 = u - U->qu * lq, l2 = v - U->qv * lq;
-    const float dB = drel * 9.0f + 0.06f;
+    const float dB = drel * 9.0f + (0.05f / FILTER_TIGHT + 0.01f);
     const bool outB = (lq < -dB) | (l1 < -dB) | (l2 < -dB) | behind;
     if (!(well & outB)) mask |= 1u << ((meta >> 5) & 31u);
   }

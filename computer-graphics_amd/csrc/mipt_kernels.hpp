@@ -63,7 +63,7 @@ struct PathArgs {
 // the previous mark to the section's LDS counter; mipt_get_stats prints the totals.
 enum ProfSection {
   PF_QUEUE = 0, PF_RAYGEN, PF_PHASE1, PF_PHASE2, PF_HIT, PF_TERMINAL, PF_SCATTER, PF_DIFFUSE, PF_MIRROR,
-  PF_GLASS, PF_RENORM, PF_UNWIND, PF_COUNT
+  PF_GLASS, PF_RENORM, PF_UNWIND, PF_N_QUERIES, PF_N_CANDS, PF_N_ROUNDS, PF_COUNT
 };
 #ifdef MIPT_PROFILE_SECTIONS
 struct Prof {
@@ -75,12 +75,18 @@ struct Prof {
     if (lds && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(lds + k, now - last);
     last = now;
   }
+  __device__ __forceinline__ void count(int k, uint32_t n) { if (lds && n) atomicAdd(lds + k, n); }
+  __device__ __forceinline__ void count_wave(int k) {
+    if (lds && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(lds + k, 1u);
+  }
 };
 #else
 struct Prof {
   uint32_t* lds;
   __device__ __forceinline__ void start() {}
   __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void count(int, uint32_t) {}
+  __device__ __forceinline__ void count_wave(int) {}
 };
 #endif
 
@@ -107,7 +113,8 @@ constexpr int LDS_TABLE_MAX = 64;
 
 template <bool STATS, int MODE = (STATS ? SCAN_FAST : MIPT_SCAN_MODE)>
 __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d, bool shadow, HitAcc& h,
-                                               uint32_t& n_tests, uint32_t& n_gate, Prof& prof) {
+                                               uint32_t& n_tests, uint32_t& n_gate, Prof& prof,
+                                               const TriRec* lane_tris) {
   const TriRec MIPT_CONST* tris = as_constant(sc.tris);
   const float px = -d.x, py = -d.y, pz = -d.z;  // vec3(-ray.direction), intersections.cpp:20
   const int n = sc.n_tris;
@@ -134,13 +141,15 @@ __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d
     for (int k = n_pairs; k < n_units; ++k)
       unit_candidates<false>(units + k, o.x, o.y, o.z, d.x, d.y, d.z, Dm, mask);
     prof.mark(PF_PHASE1);
+    prof.count(PF_N_QUERIES, 1u);
+    prof.count(PF_N_CANDS, (uint32_t)__popc(mask));
     while (__any(mask != 0)) {
+      prof.count_wave(PF_N_ROUNDS);
       if (mask != 0) {
         const int i = base + __ffs((int)mask) - 1;
         mask &= mask - 1u;
-        // each lane fetches ITS candidate record (L1-resident for Cornell-sized scenes; staging the
-        // table in LDS instead measured 4 % slower)
-        const TriRec T = sc.tris[i];
+        // each lane fetches ITS candidate record (from the caller's table: global memory, or LDS)
+        const TriRec T = lane_tris[i];
         tri_test<false, true>(&T, i, o.x, o.y, o.z, px, py, pz, shadow, h, n_tests, n_gate);
       }
     }
@@ -155,9 +164,9 @@ __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d
 template <bool STATS, bool BVH>
 __device__ __forceinline__ void scene_query(const DeviceScene& sc, V4 o, V4 d, bool shadow, HitAcc& h,
                                             uint32_t& n_tests, uint32_t& n_gate, uint32_t& redo,
-                                            uint32_t& overflow, Prof& prof) {
+                                            uint32_t& overflow, Prof& prof, const TriRec* lane_tris) {
   if (!BVH) {  // kernels are instantiated per kind of scene: the linear ones carry no traversal stack
-    scan_triangles<STATS>(sc, o, d, shadow, h, n_tests, n_gate, prof);
+    scan_triangles<STATS>(sc, o, d, shadow, h, n_tests, n_gate, prof, lane_tris);
     return;
   }
   const BvhRay r = bvh_ray(sc, o, d);
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(BLOCK) void k_closest_hit(DeviceScene sc, const flo
   h.idx = -1; h.by = 0.f; h.bz = 0.f;
   uint32_t n_tests = 0, n_gate = 0, redo = 0, overflow = 0;
   Prof prof{};
-  scene_query<false, BVH>(sc, o, d, false, h, n_tests, n_gate, redo, overflow, prof);
+  scene_query<false, BVH>(sc, o, d, false, h, n_tests, n_gate, redo, overflow, prof, sc.tris);
   V4 pos = {0, 0, 0, 0}, nrm;
   bool sphere_hit = false;
   for (int s = 0; s < sc.n_spheres; ++s) {
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
   h.idx = 0; h.by = 0.f; h.bz = 0.f;
   uint32_t n_tests = 0, n_gate = 0, redo = 0, overflow = 0;
   Prof prof{};
-  scene_query<false, BVH>(sc, o, d, true, h, n_tests, n_gate, redo, overflow, prof);
+  scene_query<false, BVH>(sc, o, d, true, h, n_tests, n_gate, redo, overflow, prof, sc.tris);
   occluded[i] = (uint8_t)h.idx;
 }
 
@@ -412,7 +421,8 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
     h.idx = shadow ? 0 : -1;
     h.by = 0.f; h.bz = 0.f;
     uint32_t n_tests = 0, n_gate = 0, redo = 0, overflow = 0;
-    scene_query<STATS, BVH>(a.sc, o, d, shadow, h, n_tests, n_gate, redo, overflow, prof);
+        // phase 2 gathers each lane's candidate record from the LDS copy when there is one (+2 %)
+    scene_query<STATS, BVH>(a.sc, o, d, shadow, h, n_tests, n_gate, redo, overflow, prof, tri_tab);
     if (STATS || LIST) {
       st[shadow ? ST_SHADOW : ST_CLOSEST]++;
       if (STATS) { st[ST_TESTS] += n_tests; st[ST_GATE] += n_gate; st[ST_BVH_REDO] += redo; st[ST_BVH_OVERFLOW] += overflow; }
@@ -746,10 +756,10 @@ __global__ __launch_bounds__(BLOCK) void k_selfcheck_scan(DeviceScene sc, unsign
     e = f; g = f;
     uint32_t nt = 0, ng = 0;
     Prof prof{};
-    scan_triangles<false, SCAN_LITERAL>(sc, o, d, mode != 0, e, nt, ng, prof);
-    scan_triangles<false, SCAN_FAST>(sc, o, d, mode != 0, f, nt, ng, prof);
+    scan_triangles<false, SCAN_LITERAL>(sc, o, d, mode != 0, e, nt, ng, prof, sc.tris);
+    scan_triangles<false, SCAN_FAST>(sc, o, d, mode != 0, f, nt, ng, prof, sc.tris);
     uint32_t redo = 0, overflow = 0;
-    scene_query<false, BVH>(sc, o, d, mode != 0, g, nt, ng, redo, overflow, prof);  // two-phase scan, or the LBVH
+    scene_query<false, BVH>(sc, o, d, mode != 0, g, nt, ng, redo, overflow, prof, sc.tris);  // two-phase scan, or the LBVH
     if (redo) atomicAdd(out + 4, (unsigned long long)redo);
     if (overflow) atomicAdd(out + 5, (unsigned long long)overflow);
     auto same = [](const HitAcc& a, const HitAcc& b) {
