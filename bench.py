@@ -149,6 +149,16 @@ def main():
         torch.cuda.synchronize()
         fog_off = SIZE * SIZE * spp / (time.perf_counter() - t1)
 
+        # HBM bytes per launch of this workload, from the committed rocprofv3 --pmc passes
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic_k_paths.json")) as f:
+                tj = json.load(f)
+            if tj["size"] == SIZE and tj["spp"] == spp:
+                traffic = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
+
         line = {
             "metric": "paths/sec (+ Mrays/sec), Cornell box 1024^2, MI355X",
             "value": value, "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -163,14 +173,15 @@ def main():
             "rays_per_path": rays_per_path,
             "paths_per_s_fog_off_1gpu": fog_off,
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VECTOR, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VECTOR, "traffic": None,
+                         "frac": achieved / PEAK_FP32_VECTOR, "traffic": traffic,
                          "peak_nonfused": PEAK_FP32_NONFUSED, "frac_nonfused": achieved / PEAK_FP32_NONFUSED,
                          "kernel": "k_paths", "kernel_ms": k_ms, "flops_per_launch": flops,
                          "tri_tests": st.tri_tests, "gate_passes": st.gate_passes,
                          "note": "algorithmic flops = 26*tests + 79*gate_passes of the reference's triangle test; "
                                  "FMA contraction is forbidden by the bit-exact contract, so 78.6 TFLOP/s is the "
-                                 "issue-rate roof; HBM traffic of this kernel is negligible (22 triangles in the "
-                                 "scalar cache, 12 bytes written per 16-sample work item)"},
+                                 "issue-rate roof; traffic = HBM bytes per launch measured by rocprofv3 --pmc "
+                                 "(profiles/traffic_k_paths.json): 12 bytes written per 16-sample work item, "
+                                 "the 22 triangles stay in the scalar cache and LDS"},
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(abi, tris, cam, light, params)
