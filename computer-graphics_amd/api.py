@@ -46,6 +46,31 @@ def load_test_model(which):
     return tris[:n].copy()
 
 
+def load_obj(path):
+    """LoadObject (parser.cpp:8-46): the triangles of an OBJ file as a TRIANGLE_DTYPE array."""
+    lib = abi.load_library()
+    n = lib.mipt_load_obj(str(path).encode(), None, 0)
+    if n < 0:
+        raise MiptError(n, lib.mipt_last_error().decode())
+    tris = np.zeros(n, dtype=abi.TRIANGLE_DTYPE)
+    if n:
+        n2 = lib.mipt_load_obj(str(path).encode(), _ptr(tris), n)
+        if n2 != n:
+            raise MiptError(n2, lib.mipt_last_error().decode())
+    return tris
+
+
+def normalise_triangles(tris, scale=1.0, displacement=(0, 0, 0), rotate=(0, 0, 0), adjust_normal=(1, 1, 1),
+                        material=abi.MAT_DIFFUSE):
+    """normaliseTriangles (utils.cpp:52-140); returns a placed copy."""
+    out = np.ascontiguousarray(tris, dtype=abi.TRIANGLE_DTYPE).copy()
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    _check(abi.load_library().mipt_normalise_triangles(_ptr(out) if len(out) else None, len(out), float(scale),
+                                                       C.byref(f3(displacement)), C.byref(f3(rotate)),
+                                                       C.byref(f3(adjust_normal)), int(material)))
+    return out
+
+
 def default_camera(width):
     cam = abi.MiptCamera()
     abi.load_library().mipt_default_camera(C.byref(cam), width)

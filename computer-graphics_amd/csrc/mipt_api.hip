@@ -40,6 +40,8 @@ static int fail(int code, const char* fmt, ...) {
   } while (0)
 
 extern "C" const char* mipt_last_error(void) { return g_err; }
+// for the host-only translation units of the library
+extern "C" int mipt_internal_fail(int code, const char* msg) { return fail(code, "%s", msg); }
 extern "C" const char* mipt_version(void) { return "mipt 0.1 gfx950 hip"; }
 
 // ---------------------------------------------------------------------------------------

@@ -155,6 +155,20 @@ void mipt_default_camera(MiptCamera* cam, int width);
  * the glassCube / glassCubeSphere / glassWolf scenes. */
 void mipt_default_light(MiptLight* light, int glass_scene);
 
+/* LoadObject (parser.cpp:8-46) over the objl loader it drives (OBJ_Loader.h:430-992): the triangles
+ * of a Wavefront OBJ file in file order, bit for bit what the reference builds -- positions through
+ * strtof, w = 1, colour (1,1,1), material diffuse, normal = (x, y of the first vertex' normal, z of
+ * the SECOND vertex' normal, 1), a face without normals carrying the unnormalised (P0-P1) x (P2-P1),
+ * polygons cut the way objl cuts them. Returns the number of triangles in the file (call with
+ * out = NULL to size the buffer; at most `capacity` are written) or a MiptError. */
+int mipt_load_obj(const char* path, MiptTriangle* out, size_t capacity);
+/* normaliseTriangles (utils.cpp:52-140), in place: divide all four components of every vertex by
+ * scale * L (L = largest |coordinate| of the set), add the displacement, rotate by Rx Ry Rz; recompute
+ * a normal whose x is exactly 0, scale normals by adjust_normal, rotate them, set the material.
+ * main.cpp:84-88 places the wolf with (1, {-0.2,-1,-0.5}, {3.15,-2.5,0}, {-1,1,1}, glass). */
+int mipt_normalise_triangles(MiptTriangle* tris, size_t n, float scale, const float displacement[3],
+                             const float rotate[3], const float adjust_normal[3], uint32_t material);
+
 const char* mipt_last_error(void);
 /* "mipt <version> gfx950 hip" */
 const char* mipt_version(void);

@@ -116,3 +116,48 @@ def test_tree_render_matches_oracle(api, O, dtype):
     assert (st.closest_rays, st.shadow_rays) == (ost.closest_rays, ost.shadow_rays)
     same = (bits(img) == bits(ref)).all(axis=2).mean()
     assert same > 0.995, same
+
+
+def glasswolf_scene(pkg):
+    """The reference's glassWolf scene (main.cpp:78-89), as dumped from the reference's own loader
+    code: 10 room triangles + 1784 glass triangles with unnormalised normals and w = 1/L vertices."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "obj", "glasswolf_scene.bin")
+    return np.fromfile(path, dtype=pkg.abi.TRIANGLE_DTYPE)
+
+
+def test_glasswolf_tree_equals_linear_scan(api, O, pkg):
+    tris = glasswolf_scene(pkg)
+    sc = api.Scene(tris)
+    assert sc.bvh_info()[0]
+    _, _, closest_bad, any_bad = sc.selfcheck(1 << 22, seed=9)
+    redo, overflow = sc.last_selfcheck_bvh
+    assert (closest_bad, any_bad, overflow) == (0, 0, 0), (closest_bad, any_bad, overflow)
+    n = 1 << 13
+    for kind, (o, d) in {"primary": raygen.primary_rays(n), "interior": raygen.interior_rays(n),
+                         "surface": raygen.surface_rays(tris, n)}.items():
+        idx, t, pos = sc.closest_hit(o, d)
+        oidx, ot, opos = O.closest_hit(tris, None, o, d)
+        assert np.array_equal(idx, oidx), (kind, np.count_nonzero(idx != oidx))
+        hit = oidx >= 0
+        assert np.array_equal(bits(t[hit]), bits(ot[hit])), kind
+        assert np.array_equal(bits(pos[hit]), bits(opos[hit])), kind
+        if kind == "primary":
+            assert (idx >= 10).mean() > 0.02   # the wolf is in view
+    sc.close()
+
+
+def test_glasswolf_paths_match_oracle(api, O, pkg):
+    tris = glasswolf_scene(pkg)
+    W = H = 32
+    cam, light = api.default_camera(W), api.default_light(True)
+    p = api.default_params(W, H, flags=1)
+    sc = api.Scene(tris)
+    img = sc.render_accumulate(cam, light, p, 0, 4)
+    st = sc.stats()
+    sc.close()
+    ref, ost = O.render_accumulate(tris, None, cam, light, p, 0, 4)
+    assert (st.closest_rays, st.shadow_rays, st.glass_bounces) == (ost.closest_rays, ost.shadow_rays, ost.glass_bounces)
+    assert st.glass_bounces > 100
+    same = (bits(img) == bits(ref)).all(axis=2).mean()
+    assert same > 0.99, same
