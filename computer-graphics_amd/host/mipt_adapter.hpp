@@ -173,4 +173,46 @@ inline void Draw(GpuScene& gpu, ScreenT* screen, const CameraT& cam, const Light
   check(mipt_resolve_argb(gpu.handle(), accum.data(), W, H, (uint32_t)samplesSeenSoFar, screen->buffer));
 }
 
+// LoadObject (parser.cpp:8-46): appends the OBJ file's triangles, built with the reference's own
+// five-argument Triangle constructor (TestModelH.h:20-24).
+template <class TriangleT>
+inline void LoadObject(const std::string& path, std::vector<TriangleT>& triangles) {
+  const int n = mipt_load_obj(path.c_str(), nullptr, 0);
+  if (n < 0) check(n);
+  std::vector<MiptTriangle> m((size_t)n);
+  if (n) check(mipt_load_obj(path.c_str(), m.data(), m.size()) == n ? MIPT_OK : MIPT_E_INVALID);
+  typedef decltype(TriangleT::v0) V4;
+  typedef decltype(TriangleT::color) V3;
+  for (const MiptTriangle& t : m)
+    triangles.push_back(TriangleT(V4(t.v0[0], t.v0[1], t.v0[2], t.v0[3]), V4(t.v1[0], t.v1[1], t.v1[2], t.v1[3]),
+                                  V4(t.v2[0], t.v2[1], t.v2[2], t.v2[3]), V3(t.color[0], t.color[1], t.color[2]),
+                                  V4(t.normal[0], t.normal[1], t.normal[2], t.normal[3])));
+}
+
+// normaliseTriangles (utils.cpp:52-140), same argument list; `type` must be a string that outlives
+// the triangles (the reference stores the pointer, material.h:5-11).
+template <class TriangleT>
+inline void normaliseTriangles(std::vector<TriangleT>& raw, float scale = 1, float displacementX = 0,
+                               float displacementY = 0, float displacementZ = 0, float rotateX = 0,
+                               float rotateY = 0, float rotateZ = 0, float adjustNormalX = 1,
+                               float adjustNormalY = 1, float adjustNormalZ = 1, const char* type = "diffuse") {
+  std::vector<MiptTriangle> m;
+  m.reserve(raw.size());
+  for (const auto& t : raw) m.push_back(to_mipt(t));
+  const float d[3] = {displacementX, displacementY, displacementZ}, r[3] = {rotateX, rotateY, rotateZ};
+  const float a[3] = {adjustNormalX, adjustNormalY, adjustNormalZ};
+  // the library's material codes cover the four strings the path dispatches on; any other string
+  // behaves like "none" on the path, and the triangle keeps the caller's pointer either way
+  check(mipt_normalise_triangles(m.data(), m.size(), scale, d, r, a, material_code(type)));
+  for (size_t i = 0; i < raw.size(); ++i) {
+    auto& t = raw[i];
+    const MiptTriangle& s = m[i];
+    t.v0.x = s.v0[0]; t.v0.y = s.v0[1]; t.v0.z = s.v0[2]; t.v0.w = s.v0[3];
+    t.v1.x = s.v1[0]; t.v1.y = s.v1[1]; t.v1.z = s.v1[2]; t.v1.w = s.v1[3];
+    t.v2.x = s.v2[0]; t.v2.y = s.v2[1]; t.v2.z = s.v2[2]; t.v2.w = s.v2[3];
+    t.normal.x = s.normal[0]; t.normal.y = s.normal[1]; t.normal.z = s.normal[2]; t.normal.w = s.normal[3];
+    t.material.type = type;
+  }
+}
+
 }  // namespace mipt_host

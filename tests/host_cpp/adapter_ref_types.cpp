@@ -17,7 +17,19 @@ struct Camera { float focalLength; glm::vec4 cameraPos; glm::mat4 cameraRotation
 struct Light { glm::vec4 lightPos; glm::vec3 lightColor; };
 struct Sphere { float radius; glm::vec4 center; glm::vec3 color; Material material; };
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc == 2) {  // glassWolf through the adapter's LoadObject / normaliseTriangles (main.cpp:78-89)
+    std::vector<Triangle> scene, wolf;
+    LoadTestModelNone(scene);
+    mipt_host::LoadObject(argv[1], wolf);
+    mipt_host::normaliseTriangles(wolf, 1.0, -0.2, -1, -0.5, 3.15, -2.5, 0, -1, 1, 1, "glass");
+    scene.insert(scene.end(), wolf.begin(), wolf.end());
+    for (const Triangle& t : scene) {
+      MiptTriangle m = mipt_host::to_mipt(t);
+      fwrite(&m, sizeof m, 1, stdout);
+    }
+    return 0;
+  }
   void (*loaders[4])(std::vector<Triangle>&) = {LoadTestModel, LoadTestModelColorBleeding, LoadTestModelGlassCube,
                                                LoadTestModelNone};
   for (auto load : loaders) {

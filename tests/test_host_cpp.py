@@ -44,6 +44,11 @@ def test_adapter_accepts_reference_types(tmp_path, pkg, O):
     sph = np.frombuffer(blob, dtype=abi.SPHERE_DTYPE, count=1, offset=off)
     assert sph["material"][0] == abi.MAT_GLASS and sph["radius"][0] == np.float32(0.3)
     assert len(blob) == off + 36
+    # LoadObject + normaliseTriangles through the adapter, into the reference's own Triangle type
+    wolf = os.path.join(ROOT, "tests", "golden", "obj", "wolf.obj")
+    blob = subprocess.run([exe, wolf], check=True, capture_output=True).stdout
+    ref = np.fromfile(os.path.join(ROOT, "tests", "golden", "obj", "glasswolf_scene.bin"), dtype=abi.TRIANGLE_DTYPE)
+    assert blob == ref.tobytes()
 
 
 @pytest.mark.gpu
