@@ -389,6 +389,12 @@ extern "C" int mipt_scene_has_bvh(MiptScene* s, uint64_t* n_nodes, double* build
   return 1;
 }
 
+// persistent grid of the tree batch kernels: enough workgroups to fill the chip, no more than the rays need
+static inline unsigned batch_grid(size_t n_rays) {
+  const size_t need = (n_rays + BLOCK - 1) / BLOCK;
+  return (unsigned)(need < PERSISTENT_BLOCKS ? need : PERSISTENT_BLOCKS);
+}
+
 extern "C" int mipt_scene_pair_units(MiptScene* s) { return s ? (int)s->n_pair_units : 0; }
 
 extern "C" int mipt_closest_hit_dev(MiptScene* s, const float* d_origin4, const float* d_dir4, size_t n_rays,
@@ -398,11 +404,13 @@ extern "C" int mipt_closest_hit_dev(MiptScene* s, const float* d_origin4, const 
   if (!d_origin4 || !d_dir4 || !d_tri_idx || !d_t) return fail(MIPT_E_INVALID, "mipt_closest_hit: null buffer");
   if (n_rays > ((size_t)1 << 31) * BLOCK) return fail(MIPT_E_INVALID, "mipt_closest_hit: too many rays");
   HIP_TRY(hipSetDevice(s->device));
-  if (s->d.bvh)
-    hipLaunchKernelGGL(k_closest_hit<true>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
-                       (const float4*)d_origin4, (const float4*)d_dir4, n_rays, d_tri_idx, d_t,
-                       (float4*)d_position4);
-  else
+  if (s->d.bvh) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(s->d_queue) + 2;
+    HIP_TRY(hipMemsetAsync(q, 0, 8, (hipStream_t)stream));
+    hipLaunchKernelGGL(k_bvh_batch<false>, dim3(batch_grid(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
+                       (const float4*)d_origin4, (const float4*)d_dir4, (const float*)nullptr,
+                       (unsigned long long)n_rays, q, d_tri_idx, d_t, (float4*)d_position4, (uint8_t*)nullptr);
+  } else
     hipLaunchKernelGGL(k_closest_hit<false>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
                        (const float4*)d_origin4, (const float4*)d_dir4, n_rays, d_tri_idx, d_t,
                        (float4*)d_position4);
@@ -417,10 +425,13 @@ extern "C" int mipt_any_hit_dev(MiptScene* s, const float* d_origin4, const floa
   if (!d_origin4 || !d_dir4 || !d_max_t || !d_occluded) return fail(MIPT_E_INVALID, "mipt_any_hit: null buffer");
   if (n_rays > ((size_t)1 << 31) * BLOCK) return fail(MIPT_E_INVALID, "mipt_any_hit: too many rays");
   HIP_TRY(hipSetDevice(s->device));
-  if (s->d.bvh)
-    hipLaunchKernelGGL(k_any_hit<true>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
-                       (const float4*)d_origin4, (const float4*)d_dir4, d_max_t, n_rays, d_occluded);
-  else
+  if (s->d.bvh) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(s->d_queue) + 2;
+    HIP_TRY(hipMemsetAsync(q, 0, 8, (hipStream_t)stream));
+    hipLaunchKernelGGL(k_bvh_batch<true>, dim3(batch_grid(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
+                       (const float4*)d_origin4, (const float4*)d_dir4, d_max_t, (unsigned long long)n_rays, q,
+                       (int32_t*)nullptr, (float*)nullptr, (float4*)nullptr, d_occluded);
+  } else
     hipLaunchKernelGGL(k_any_hit<false>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
                        (const float4*)d_origin4, (const float4*)d_dir4, d_max_t, n_rays, d_occluded);
   HIP_TRY(hipGetLastError());
@@ -722,7 +733,7 @@ extern "C" int mipt_get_stats(MiptScene* s, MiptStats* out) {
     out->tri_tests = h[ST_TESTS]; out->gate_passes = h[ST_GATE];
     out->sphere_tests = h[ST_SPHERE]; out->fog_events = h[ST_FOG];
     out->diffuse_bounces = h[ST_DIFFUSE]; out->mirror_bounces = h[ST_MIRROR]; out->glass_bounces = h[ST_GLASS];
-    out->bvh_redo = h[ST_BVH_REDO]; out->bvh_overflow = h[ST_BVH_OVERFLOW];
+    out->bvh_redo = h[ST_BVH_REDO]; out->bvh_overflow = h[ST_BVH_OVERFLOW]; out->bvh_nodes = h[ST_BVH_NODES];
   }
   return MIPT_OK;
 }

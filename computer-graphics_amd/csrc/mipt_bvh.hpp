@@ -222,6 +222,15 @@ struct BvhHit { int idx; float t, z, by, bz; };
 // A tree over sorted 63-bit keys, equal keys split by their 32-bit position, is at most 95 levels
 // deep, and the traversal pushes at most one entry per level: the stack cannot overflow.
 constexpr int BVH_STACK = 96;
+// a burst of the walk ends when fewer than KEEP_NUM / KEEP_DEN of the lanes that entered it still walk
+#ifndef MIPT_BVH_KEEP_NUM
+#define MIPT_BVH_KEEP_NUM 1
+#endif
+#ifndef MIPT_BVH_KEEP_DEN
+#define MIPT_BVH_KEEP_DEN 2
+#endif
+constexpr int BVH_KEEP_NUM = MIPT_BVH_KEEP_NUM, BVH_KEEP_DEN = MIPT_BVH_KEEP_DEN;
+constexpr int BVH_DONE = (int)0x80000000;  // traversal finished (leaf references are -1 - index > this)
 constexpr int BVH_LIST = 8;               // hits kept by the pruned traversal
 constexpr float BVH_BAND = 1.001953125f;  // 1 + 2^-9
 
@@ -241,6 +250,7 @@ struct BvhRay {
   V4 o, d;
   V3 oo, inv;
   float px, py, pz, Dm, delta;
+  uint32_t n_nodes, n_leaves;  // work counters (dead code unless the caller reads them)
 };
 
 __device__ __forceinline__ BvhRay bvh_ray(const DeviceScene& sc, V4 o, V4 d) {
@@ -254,6 +264,7 @@ __device__ __forceinline__ BvhRay bvh_ray(const DeviceScene& sc, V4 o, V4 d) {
   // absolute slack on ray parameters: the determinant ratio of a triangle the origin lies on is
   // rounding noise of about 2^-23 (|o| + |v|) / (|d| cos(angle to the normal))
   r.delta = sane ? 0.0001220703125f * (sc.scale + Om) / Dabs : 0.f;  // 2^-13
+  r.n_nodes = 0; r.n_leaves = 0;
   r.oo = {o.x, o.y, o.z};
   r.inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
   return r;
@@ -271,74 +282,118 @@ __device__ __forceinline__ bool bvh_leaf(const DeviceScene& sc, const BvhRay& r,
          (x1 + x2) <= __uint_as_float(0x3F8020C4u);
 }
 
-// Closest hit through the tree with distance pruning. Returns false if the ray has to be redone
-// by bvh_closest_exhaustive (a hit whose t and z disagree, or more near-ties than the list holds).
-__device__ __forceinline__ bool bvh_closest(const DeviceScene& sc, const BvhNode* __restrict__ nodes,
-                                            const BvhRay& r, HitAcc& h, uint32_t& overflow) {
-  BvhHit list[BVH_LIST];
-  int n_list = 0;
-  float zmin = 3.402823466e+38f, bound = 3.402823466e+38f;
+// State of one ray's walk through the tree. The walk is resumable: bvh_burst advances it until it
+// is finished or until too few lanes of the wave are still walking, so that a caller can hand
+// finished lanes new work instead of letting them wait for the longest walk of the wave (walk
+// lengths are heavy tailed: a wave that waits for its slowest ray runs at ~10 % lane occupancy).
+struct BvhTrav {
+  int cur;        // node (>= 0), leaf (< 0) or BVH_DONE
+  int sp, n_list;
+  float zmin, bound;
+  bool redo;      // closest: the pruned walk cannot vouch for this ray, run bvh_closest_exhaustive
+  bool hit;       // any-hit: a triangle accepted
+};
+// The walk's arrays live beside the scalar state, not inside it: a struct holding dynamically
+// indexed arrays is kept in scratch memory as a whole, scalars included.
+struct BvhMem {
   int stack[BVH_STACK];
-  int sp = 0;
-  int cur = sc.n_tris > 1 ? 0 : -1;  // a single triangle is its own tree
-  for (;;) {
-    if (cur < 0) {
-      const int i = -1 - cur;
+  BvhHit list[BVH_LIST];  // closest: surviving hits, sorted by triangle index
+};
+
+__device__ __forceinline__ void bvh_begin(BvhTrav& T, const DeviceScene& sc, const BvhRay& r, bool shadow,
+                                          float max_t) {
+  T.cur = sc.n_tris > 1 ? 0 : -1;  // a single triangle is its own tree
+  T.sp = 0; T.n_list = 0;
+  T.zmin = 3.402823466e+38f;
+  // any-hit: t of an accepted triangle is <= max_t; its true distance can exceed that by the filter's slack
+  T.bound = shadow ? fabsf(max_t) * 1.05f + 4.0f * r.delta + 1e-30f : 3.402823466e+38f;
+  T.redo = false; T.hit = false;
+}
+
+// "while-while": all walking lanes step through inner nodes until each holds a leaf (or is done),
+// then all test their leaves -- the two kinds of work are not interleaved lane by lane.
+// Closest hit (shadow = false): distance pruning + near-tie list, see the head of this file.
+// Any hit: existsIntersection is an OR over the triangles, the walk stops at the first acceptance.
+// Returns when the lane's walk is done or when fewer than `keep_num / keep_den` of the lanes that
+// entered are still walking.
+__device__ __forceinline__ void bvh_burst(BvhTrav& T, BvhMem& M, const DeviceScene& sc, const BvhNode* __restrict__ nodes,
+                                          BvhRay& r, bool shadow, float max_t, uint32_t& overflow) {
+  const int entered = __popcll(__ballot(T.cur != BVH_DONE));
+  while (T.cur != BVH_DONE) {
+    while (T.cur >= 0) {
+      const BvhNode N = nodes[T.cur];
+      r.n_nodes++;
+      float tl, tr;
+      const bool hl = slab(N.lmin, N.lmax, r.oo, r.inv, T.bound, tl);
+      const bool hr = slab(N.rmin, N.rmax, r.oo, r.inv, T.bound, tr);
+      if (hl && hr) {
+        const bool left_first = tl <= tr;
+        if (T.sp >= BVH_STACK) { overflow++; T.redo = true; T.cur = BVH_DONE; break; }
+        M.stack[T.sp++] = left_first ? N.right : N.left;
+        T.cur = left_first ? N.left : N.right;
+      } else if (hl || hr) {
+        T.cur = hl ? N.left : N.right;
+      } else {
+        T.cur = T.sp ? M.stack[--T.sp] : BVH_DONE;
+      }
+    }
+    if (T.cur != BVH_DONE) {
+      const int i = -1 - T.cur;
       float t, z, x1, x2;
+      r.n_leaves++;
+      T.cur = T.sp ? M.stack[--T.sp] : BVH_DONE;
       if (bvh_leaf(sc, r, i, t, z, x1, x2)) {
-        if (!(fabsf(t - z) <= 0.000244140625f * z + r.delta)) return false;  // 2^-12
-        if (z < zmin) {
-          zmin = z;
-          bound = zmin * BVH_BAND + 4.0f * r.delta;
-          int w = 0;  // drop hits that fell out of the band
-          for (int k = 0; k < n_list; ++k)
-            if (list[k].t <= bound) list[w++] = list[k];
-          n_list = w;
-        }
-        if (t <= bound) {
-          if (n_list == BVH_LIST) return false;
-          int k = n_list++;
-          while (k > 0 && list[k - 1].idx > i) { list[k] = list[k - 1]; --k; }  // keep index order
-          list[k] = {i, t, z, x1, x2};
+        if (shadow) {
+          if (t <= max_t && (x1 + x2) <= 1.0f) { T.hit = true; T.cur = BVH_DONE; }  // intersections.cpp:75-77
+        } else {
+          if (!(fabsf(t - z) <= 0.000244140625f * z + r.delta)) { T.redo = true; T.cur = BVH_DONE; }  // 2^-12
+          if (z < T.zmin) {
+            T.zmin = z;
+            T.bound = T.zmin * BVH_BAND + 4.0f * r.delta;
+            int w = 0;  // drop hits that fell out of the band
+            for (int k = 0; k < T.n_list; ++k)
+              if (M.list[k].t <= T.bound) M.list[w++] = M.list[k];
+            T.n_list = w;
+          }
+          if (t <= T.bound) {
+            if (T.n_list == BVH_LIST) {
+              T.redo = true; T.cur = BVH_DONE;
+            } else {
+              int k = T.n_list++;
+              while (k > 0 && M.list[k - 1].idx > i) { M.list[k] = M.list[k - 1]; --k; }  // keep index order
+              M.list[k] = {i, t, z, x1, x2};
+            }
+          }
         }
       }
-      if (sp == 0) break;
-      cur = stack[--sp];
-      continue;
     }
-    const BvhNode N = nodes[cur];
-    float tl, tr;
-    const bool hl = slab(N.lmin, N.lmax, r.oo, r.inv, bound, tl);
-    const bool hr = slab(N.rmin, N.rmax, r.oo, r.inv, bound, tr);
-    if (hl && hr) {
-      const bool left_first = tl <= tr;
-      if (sp >= BVH_STACK) { overflow++; return false; }
-      stack[sp++] = left_first ? N.right : N.left;
-      cur = left_first ? N.left : N.right;
-    } else if (hl || hr) {
-      cur = hl ? N.left : N.right;
-    } else {
-      if (sp == 0) break;
-      cur = stack[--sp];
-    }
+    // lanes still walking (this ballot is taken by the lanes inside the loop only)
+    if (BVH_KEEP_DEN * (int)__popcll(__ballot(T.cur != BVH_DONE)) < BVH_KEEP_NUM * entered) break;
+  }
+}
+
+// result of a finished walk into the scan's accumulator (the caller handles T.redo first)
+__device__ __forceinline__ void bvh_finish(const BvhTrav& T, const BvhMem& M, bool shadow, HitAcc& h) {
+  if (shadow) {
+    if (T.hit) { h.set_lim(-1.0f); h.idx = 1; }
+    return;
   }
   // the reference's sequential rule over the surviving hits, in index order (:25, :28)
-  for (int k = 0; k < n_list; ++k) {
-    if (list[k].t <= h.lim) {
-      h.set_lim(list[k].z);
-      h.idx = list[k].idx;
-      h.by = list[k].by;
-      h.bz = list[k].bz;
+  for (int k = 0; k < T.n_list; ++k) {
+    if (M.list[k].t <= h.lim) {
+      h.set_lim(M.list[k].z);
+      h.idx = M.list[k].idx;
+      h.by = M.list[k].by;
+      h.bz = M.list[k].bz;
     }
   }
-  return true;
 }
 
 // The same without any assumption about distances: the reference's scan accepts, after triangle
 // `after`, the lowest-numbered triangle that passes its test against the current limit; each
 // pass walks every box the ray touches to find that triangle, until a pass finds none.
 __device__ __forceinline__ void bvh_closest_exhaustive(const DeviceScene& sc, const BvhNode* __restrict__ nodes,
-                                                       const BvhRay& r, HitAcc& h, uint32_t& overflow) {
+                                                       BvhRay& r, HitAcc& h, uint32_t& overflow) {
   int after = -1;
   for (;;) {
     int best = 0x7FFFFFFF;
@@ -358,6 +413,7 @@ __device__ __forceinline__ void bvh_closest_exhaustive(const DeviceScene& sc, co
         continue;
       }
       const BvhNode N = nodes[cur];
+      r.n_nodes++;
       float tl, tr;
       const bool hl = slab(N.lmin, N.lmax, r.oo, r.inv, 3.402823466e+38f, tl);
       const bool hr = slab(N.rmin, N.rmax, r.oo, r.inv, 3.402823466e+38f, tr);
@@ -376,40 +432,6 @@ __device__ __forceinline__ void bvh_closest_exhaustive(const DeviceScene& sc, co
     h.set_lim(bz);
     h.idx = best; h.by = b1; h.bz = b2;
     after = best;
-  }
-}
-
-// existsIntersection through the tree: true as soon as one triangle's reference test accepts
-__device__ __forceinline__ bool bvh_any(const DeviceScene& sc, const BvhNode* __restrict__ nodes, const BvhRay& r,
-                                        float max_t, uint32_t& overflow) {
-  // t of an accepted triangle is <= max_t; its true distance can exceed that by the filter's slack
-  const float bound = fabsf(max_t) * 1.05f + 4.0f * r.delta + 1e-30f;
-  int stack[BVH_STACK];
-  int sp = 0;
-  int cur = sc.n_tris > 1 ? 0 : -1;
-  for (;;) {
-    if (cur < 0) {
-      const int i = -1 - cur;
-      float t, z, x1, x2;
-      if (bvh_leaf(sc, r, i, t, z, x1, x2) && t <= max_t && (x1 + x2) <= 1.0f) return true;  // :75-77
-      if (sp == 0) return false;
-      cur = stack[--sp];
-      continue;
-    }
-    const BvhNode N = nodes[cur];
-    float tl, tr;
-    const bool hl = slab(N.lmin, N.lmax, r.oo, r.inv, bound, tl);
-    const bool hr = slab(N.rmin, N.rmax, r.oo, r.inv, bound, tr);
-    if (hl && hr) {
-      if (sp >= BVH_STACK) { overflow++; return false; }
-      stack[sp++] = N.right;
-      cur = N.left;
-    } else if (hl || hr) {
-      cur = hl ? N.left : N.right;
-    } else {
-      if (sp == 0) return false;
-      cur = stack[--sp];
-    }
   }
 }
 

@@ -164,24 +164,27 @@ __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d
 template <bool STATS, bool BVH>
 __device__ __forceinline__ void scene_query(const DeviceScene& sc, V4 o, V4 d, bool shadow, HitAcc& h,
                                             uint32_t& n_tests, uint32_t& n_gate, uint32_t& redo,
-                                            uint32_t& overflow, Prof& prof, const TriRec* lane_tris) {
+                                            uint32_t& overflow, Prof& prof, const TriRec* lane_tris,
+                                            uint32_t* n_nodes = nullptr) {
   if (!BVH) {  // kernels are instantiated per kind of scene: the linear ones carry no traversal stack
     scan_triangles<STATS>(sc, o, d, shadow, h, n_tests, n_gate, prof, lane_tris);
     return;
   }
-  const BvhRay r = bvh_ray(sc, o, d);
-  if (shadow) {
-    if (bvh_any(sc, sc.bvh, r, h.lim, overflow)) {
-      h.set_lim(-1.0f);
-      h.idx = 1;
-    }
+  // blocking form of the resumable walk: every lane stays until its own ray is done
+  BvhRay r = bvh_ray(sc, o, d);
+  BvhTrav T;
+  BvhMem M;
+  bvh_begin(T, sc, r, shadow, h.lim);
+  while (T.cur != BVH_DONE) bvh_burst(T, M, sc, sc.bvh, r, shadow, h.lim, overflow);
+  if (T.redo) {
+    redo++;
+    bvh_closest_exhaustive(sc, sc.bvh, r, h, overflow);
   } else {
-    const HitAcc h0 = h;
-    if (!bvh_closest(sc, sc.bvh, r, h, overflow)) {
-      h = h0;
-      redo++;
-      bvh_closest_exhaustive(sc, sc.bvh, r, h, overflow);
-    }
+    bvh_finish(T, M, shadow, h);
+  }
+  if (STATS) {  // tree scenes: tests = leaves whose triangle was looked at, nodes = inner nodes fetched
+    n_tests += r.n_leaves;
+    if (n_nodes) *n_nodes += r.n_nodes;
   }
 }
 
@@ -240,6 +243,84 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
   Prof prof{};
   scene_query<false, BVH>(sc, o, d, true, h, n_tests, n_gate, redo, overflow, prof, sc.tris);
   occluded[i] = (uint8_t)h.idx;
+}
+
+// Batch queries against a tree scene: persistent lanes that draw rays from a queue, so a lane whose
+// walk is over takes the next ray while its neighbours finish theirs (bvh_burst returns once half
+// the wave is done). SHADOW = existsIntersection, else closestIntersection incl. the spheres.
+template <bool SHADOW>
+__global__ __launch_bounds__(BLOCK) void k_bvh_batch(DeviceScene sc, const float4* __restrict__ origin,
+                                                     const float4* __restrict__ dir,
+                                                     const float* __restrict__ max_t, unsigned long long n_rays,
+                                                     unsigned long long* __restrict__ queue,
+                                                     int32_t* __restrict__ tri_idx, float* __restrict__ t_out,
+                                                     float4* __restrict__ pos_out, uint8_t* __restrict__ occluded) {
+  const int lane = threadIdx.x & 63;
+  BvhTrav T;
+  BvhMem M;
+  T.cur = BVH_DONE;
+  BvhRay r = {};
+  unsigned long long my = 0;
+  float lim0 = 0.f;
+  bool have = false, drained = false;
+  uint32_t overflow = 0;
+  for (;;) {
+    const unsigned long long need = __ballot(!have);
+    if (need && !drained) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(queue, (unsigned long long)__popcll(need));
+      base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+             (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)base);
+      if (base >= n_rays) drained = true;
+      const unsigned long long idx = base + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
+      if (!have && idx < n_rays) {
+        my = idx;
+        const float4 of = origin[my], df = dir[my];
+        r = bvh_ray(sc, {of.x, of.y, of.z, of.w}, {df.x, df.y, df.z, df.w});
+        lim0 = SHADOW ? max_t[my] : 3.402823466e+38f;
+        bvh_begin(T, sc, r, SHADOW, lim0);
+        have = true;
+      }
+    }
+    if (!__any(have)) break;  // every lane idle: the queue has run dry
+    if (have) {
+      bvh_burst(T, M, sc, sc.bvh, r, SHADOW, lim0, overflow);
+      if (T.cur == BVH_DONE) {
+        HitAcc h;
+        h.set_lim(lim0);
+        h.idx = SHADOW ? 0 : -1; h.by = 0.f; h.bz = 0.f;
+        if (T.redo) bvh_closest_exhaustive(sc, sc.bvh, r, h, overflow);
+        else bvh_finish(T, M, SHADOW, h);
+        if (SHADOW) {
+          occluded[my] = (uint8_t)h.idx;
+        } else {
+          V4 pos = {0, 0, 0, 0}, nrm;
+          bool sphere_hit = false;
+          for (int s = 0; s < sc.n_spheres; ++s) {
+            if (sphere_test(sc.spheres[s], r.o, r.d, h.lim, pos, nrm)) {
+              h.idx = sc.n_tris + s;
+              sphere_hit = true;
+            }
+          }
+          tri_idx[my] = h.idx;
+          if (h.idx >= 0) {
+            t_out[my] = h.lim;
+            if (pos_out) {
+              if (!sphere_hit) {  // intersections.cpp:29
+                const TriRec Tr = sc.tris[h.idx];
+                pos.x = (Tr.v0x + h.by * Tr.e1x) + h.bz * Tr.e2x;
+                pos.y = (Tr.v0y + h.by * Tr.e1y) + h.bz * Tr.e2y;
+                pos.z = (Tr.v0z + h.by * Tr.e1z) + h.bz * Tr.e2z;
+                pos.w = (Tr.v0w + h.by * 0.0f) + h.bz * 0.0f;
+              }
+              pos_out[my] = make_float4(pos.x, pos.y, pos.z, pos.w);
+            }
+          }
+        }
+        have = false;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -318,6 +399,10 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   float* sph_n = reinterpret_cast<float*>(lds_stack + (size_t)P.max_depth * BLOCK);
   const bool fog = P.fog_sigma_t > 0.f;
   constexpr bool BVH = KIND == SCENE_BVH;
+  BvhTrav trav;      // tree scenes: the lane's walk, resumable across iterations of the main loop
+  BvhMem trav_mem;
+  trav.cur = BVH_DONE;
+  bool walking = false;
   // per-primitive records the shading reads by hit index: from LDS for small scenes
   const TriRec* tri_tab = a.sc.tris;
   const ShadeRec* shade_tab = a.sc.shade;
@@ -395,8 +480,17 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       continue;
     }
     prof.mark(PF_QUEUE);
+    // A lane is `ready` for shading when its scene query has an answer. The linear scan answers
+    // within the iteration; a walk through the tree may span several (bvh_burst returns when half
+    // of the walking lanes are done, so finished lanes shade and start their next ray instead of
+    // waiting for the longest walk of the wave).
+    bool ready = false;
+    HitAcc h;
+    h.set_lim(3.402823466e+38f);
+    h.idx = -1; h.by = 0.f; h.bz = 0.f;
+    uint32_t n_tests = 0, n_gate = 0, redo = 0, overflow = 0, n_nodes = 0;
     if (have) {
-    if (fresh) {
+    if (fresh && !walking) {
       // main.cpp:124-133: two draws jitter the pixel, direction = Rx*Ry*d, not normalised
       rng_begin<RNG_MODE>(rng, pkey, s);
       const float u1 = rng_next<RNG_MODE>(rng);
@@ -416,17 +510,32 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
 
     prof.mark(PF_RAYGEN);
     // ---- one ray/scene query: closestIntersection, or existsIntersection for a shadow ray
-    HitAcc h;
-    h.set_lim(shadow ? shadow_max : 3.402823466e+38f);
-    h.idx = shadow ? 0 : -1;
-    h.by = 0.f; h.bz = 0.f;
-    uint32_t n_tests = 0, n_gate = 0, redo = 0, overflow = 0;
-        // phase 2 gathers each lane's candidate record from the LDS copy when there is one (+2 %)
-    scene_query<STATS, BVH>(a.sc, o, d, shadow, h, n_tests, n_gate, redo, overflow, prof, tri_tab);
-    if (STATS || LIST) {
-      st[shadow ? ST_SHADOW : ST_CLOSEST]++;
-      if (STATS) { st[ST_TESTS] += n_tests; st[ST_GATE] += n_gate; st[ST_BVH_REDO] += redo; st[ST_BVH_OVERFLOW] += overflow; }
+    const float lim0 = shadow ? shadow_max : 3.402823466e+38f;
+    if (BVH) {
+      BvhRay r = bvh_ray(a.sc, o, d);  // o, d stay put while the lane walks
+      if (!walking) { bvh_begin(trav, a.sc, r, shadow, lim0); walking = true; }
+      bvh_burst(trav, trav_mem, a.sc, a.sc.bvh, r, shadow, lim0, overflow);
+      n_tests = r.n_leaves; n_nodes = r.n_nodes;
+      if (trav.cur == BVH_DONE) {
+        walking = false;
+        ready = true;
+        h.set_lim(lim0);
+        h.idx = shadow ? 0 : -1;
+        if (trav.redo) { redo = 1; bvh_closest_exhaustive(a.sc, a.sc.bvh, r, h, overflow); n_tests = r.n_leaves; n_nodes = r.n_nodes; }
+        else bvh_finish(trav, trav_mem, shadow, h);
+      }
+      if (STATS) { st[ST_TESTS] += n_tests; st[ST_BVH_REDO] += redo; st[ST_BVH_OVERFLOW] += overflow; st[ST_BVH_NODES] += n_nodes; }
+    } else {
+      h.set_lim(lim0);
+      h.idx = shadow ? 0 : -1;
+      // phase 2 gathers each lane's candidate record from the LDS copy when there is one (+2 %)
+      scene_query<STATS, false>(a.sc, o, d, shadow, h, n_tests, n_gate, redo, overflow, prof, tri_tab);
+      if (STATS) { st[ST_TESTS] += n_tests; st[ST_GATE] += n_gate; }
+      ready = true;
     }
+    }  // if (have)
+    if (ready) {
+    if (STATS || LIST) st[shadow ? ST_SHADOW : ST_CLOSEST]++;
 
     bool path_done = false;
     float cr = 0.f, cg = 0.f, cb = 0.f;  // radiance at the deepest vertex when the path ends lit
@@ -652,7 +761,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
         if (!LIST) { dst[0] = sum_r; dst[1] = sum_g; dst[2] = sum_b; }
       }
     }
-    }  // if (have)
+    }  // if (ready)
     prof.mark(PF_UNWIND);
   }
 #ifdef MIPT_PROFILE_SECTIONS

@@ -137,6 +137,7 @@ typedef struct MiptStats {
   uint64_t glass_bounces;   /* bounceGlass calls */
   uint64_t bvh_redo;        /* LBVH scenes: rays re-run through the exhaustive traversal */
   uint64_t bvh_overflow;    /* LBVH scenes: rays whose stack / hit list overflowed (must be 0) */
+  uint64_t bvh_nodes;       /* LBVH scenes: inner nodes fetched (tri_tests then counts leaves visited) */
   double kernel_ms;        /* device time of the last render call's path kernel */
 } MiptStats;
 
