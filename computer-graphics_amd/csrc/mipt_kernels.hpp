@@ -344,10 +344,10 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_batch(DeviceScene sc, const float
 // applied when the path ends, deepest vertex first, from a small per-lane stack of primitive
 // tags kept in LDS.
 
-// Register budget of the path kernel: 4 waves per SIMD (<= 128 VGPRs, no spills) measured fastest
-// on the fog-on Cornell workload (5 waves spill: -12 %; 3 waves: -14 %).
+// Register budget of the path kernel: 5 waves per SIMD (<= 102 VGPRs) measured fastest on the
+// fog-on Cornell workload (4 waves: -3.5 %, 6: -3 %, 3: -16 %).
 #ifndef MIPT_WAVES_PER_EU
-#define MIPT_WAVES_PER_EU 4
+#define MIPT_WAVES_PER_EU 5
 #endif
 #define MIPT_PATHS_OCC __attribute__((amdgpu_waves_per_eu(MIPT_WAVES_PER_EU, MIPT_WAVES_PER_EU)))
 
