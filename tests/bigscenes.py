@@ -89,3 +89,44 @@ def room(O):
 def mesh_in_room(O, dtype, cells=64, nu=96, nv=48, seed=0):
     """room + heightfield + torus: 10 + 2 cells^2 + 2 nu nv triangles."""
     return np.concatenate([room(O), heightfield(dtype, cells, seed), torus(dtype, nu, nv, seed + 1)])
+
+
+def config4(O, dtype, nu=320, nv=160, seed=4, material=2):
+    """BASELINE configs[3] stand-in: the empty room (LoadTestModelNone, 10 triangles) + a closed
+    procedural mesh of 2 nu nv = 102 400 triangles (a torus displaced by a seeded wave field),
+    vertices inside [-0.6, 0.6]^3, glass by default."""
+    rng = np.random.default_rng(seed)
+    ph = rng.uniform(0, 2 * np.pi, 4)
+    u = np.linspace(0, 2 * np.pi, nu, endpoint=False)
+    v = np.linspace(0, 2 * np.pi, nv, endpoint=False)
+    du, dv = 2 * np.pi / nu, 2 * np.pi / nv
+
+    def pt(U, V):
+        rr = 0.16 * (1 + 0.18 * np.sin(5 * U + ph[0]) * np.cos(3 * V + ph[1]) + 0.05 * np.sin(17 * U + 11 * V + ph[2]))
+        R = 0.38
+        x = (R + rr * np.cos(V)) * np.cos(U)
+        z = (R + rr * np.cos(V)) * np.sin(U)
+        y = rr * np.sin(V) + 0.08 * np.sin(2 * U + ph[3])
+        return np.stack([x, y - 0.2, z], axis=-1)
+
+    U, V = np.meshgrid(u, v, indexing="ij")
+    a, b, c, d = pt(U, V), pt(U + du, V), pt(U + du, V + dv), pt(U, V + dv)
+    v0 = np.concatenate([a.reshape(-1, 3), a.reshape(-1, 3)])
+    v1 = np.concatenate([b.reshape(-1, 3), c.reshape(-1, 3)])
+    v2 = np.concatenate([c.reshape(-1, 3), d.reshape(-1, 3)])
+    n = len(v0)
+    assert np.abs(v0).max() <= 0.6
+    color = np.tile(np.array([0.75, 0.75, 0.75], dtype=np.float32), (n, 1))
+    mesh = _finish(dtype, v0, v1, v2, color, np.full(n, material, dtype=np.uint32))
+    return np.concatenate([O.load_test_model(3), mesh])
+
+
+def config5(dtype, n=1000000, seed=42):
+    """BASELINE configs[4]: n triangles, centres uniform in [-1, 1]^3, edge vectors uniform in
+    [-0.01, 0.01]^3, random diffuse colours."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    c = rng.uniform(-1, 1, (n, 3))
+    e1 = rng.uniform(-0.01, 0.01, (n, 3))
+    e2 = rng.uniform(-0.01, 0.01, (n, 3))
+    color = rng.uniform(0.1, 1.0, (n, 3)).astype(np.float32)
+    return _finish(dtype, c, c + e1, c + e2, color, np.zeros(n, dtype=np.uint32))

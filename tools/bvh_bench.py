@@ -31,12 +31,16 @@ def make_scene(name, api, dtype):
         return np.concatenate([bigscenes.room(api), bigscenes.soup(dtype, 100000, size=0.02)])
     if name == "soup1m":
         return np.concatenate([bigscenes.room(api), bigscenes.soup(dtype, 1000000, size=0.01)])
+    if name == "c4":
+        return bigscenes.config4(api, dtype)
+    if name == "c5":
+        return bigscenes.config5(dtype)
     raise SystemExit(f"unknown scene {name}")
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--scenes", default="mesh140k,soup1m")
+    ap.add_argument("--scenes", default="c4,c5")
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--rays", type=int, default=1 << 22)
@@ -63,6 +67,7 @@ def main():
         return best
 
     for name in args.scenes.split(","):
+        n = 3840 * 2160 if name == "c5" else args.rays  # configs[4] names a 3840x2160 ray batch
         tris = make_scene(name, api, abi.TRIANGLE_DTYPE)
         api.Scene(tris[:1000]).close()  # first use of the sort pays one-off set-up
         sc = api.Scene(tris)
