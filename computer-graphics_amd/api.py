@@ -71,6 +71,12 @@ def normalise_triangles(tris, scale=1.0, displacement=(0, 0, 0), rotate=(0, 0, 0
     return out
 
 
+def save_bmp(path, screen):
+    """SDL_SaveImage (SDLauxiliary.h:25-54): screen is the (H, W) uint32 ARGB buffer of resolve_argb."""
+    screen = np.ascontiguousarray(screen, dtype=np.uint32)
+    _check(abi.load_library().mipt_save_bmp(str(path).encode(), _ptr(screen), screen.shape[1], screen.shape[0]))
+
+
 def default_camera(width):
     cam = abi.MiptCamera()
     abi.load_library().mipt_default_camera(C.byref(cam), width)

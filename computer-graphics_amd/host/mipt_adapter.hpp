@@ -173,6 +173,12 @@ inline void Draw(GpuScene& gpu, ScreenT* screen, const CameraT& cam, const Light
   check(mipt_resolve_argb(gpu.handle(), accum.data(), W, H, (uint32_t)samplesSeenSoFar, screen->buffer));
 }
 
+// SDL_SaveImage (SDLauxiliary.h:25-54) for the reference's `screen` struct (buffer, width, height)
+template <class ScreenT>
+inline void SDL_SaveImage(ScreenT* s, const char* filename) {
+  check(mipt_save_bmp(filename, s->buffer, s->width, s->height));
+}
+
 // LoadObject (parser.cpp:8-46): appends the OBJ file's triangles, built with the reference's own
 // five-argument Triangle constructor (TestModelH.h:20-24).
 template <class TriangleT>

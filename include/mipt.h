@@ -170,6 +170,10 @@ int mipt_load_obj(const char* path, MiptTriangle* out, size_t capacity);
 int mipt_normalise_triangles(MiptTriangle* tris, size_t n, float scale, const float displacement[3],
                              const float rotate[3], const float adjust_normal[3], uint32_t material);
 
+/* SDL_SaveImage (SDLauxiliary.h:25-54): the ARGB8888 screen buffer as the 32-bit BI_BITFIELDS,
+ * BITMAPV4HEADER, bottom-up .bmp that SDL_SaveBMP writes for the reference's surface. */
+int mipt_save_bmp(const char* path, const uint32_t* screen_buffer, int width, int height);
+
 const char* mipt_last_error(void);
 /* "mipt <version> gfx950 hip" */
 const char* mipt_version(void);

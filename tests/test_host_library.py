@@ -93,3 +93,21 @@ def test_argument_checks_need_no_gpu(pkg, lib):
 def test_missing_library_fails_loudly(pkg, tmp_path):
     with pytest.raises(pkg.abi.MiptLibraryMissing):
         pkg.abi.load_library(str(tmp_path / "libmipt.so"))
+
+
+def test_save_bmp_writes_what_sdl_wrote_for_the_reference(pkg, lib, tmp_path):
+    # the reference ships a screenshot.bmp written by its SDL_SaveImage (500 x 500): same 122 header
+    # bytes for the same size, rows bottom-up, ARGB words untouched
+    rng = np.random.default_rng(3)
+    screen = (rng.integers(0, 1 << 24, (500, 500), dtype=np.uint32) | np.uint32(128 << 24))
+    path = tmp_path / "shot.bmp"
+    pkg.api.save_bmp(path, screen)
+    blob = path.read_bytes()
+    golden = open(os.path.join(ROOT, "tests", "golden", "screenshot_bmp_header_500x500.bin"), "rb").read()
+    assert blob[:122] == golden and len(blob) == 122 + 500 * 500 * 4
+    rows = np.frombuffer(blob, dtype="<u4", offset=122).reshape(500, 500)
+    assert np.array_equal(rows[::-1], screen)
+    assert lib.mipt_save_bmp(None, None, 4, 4) == pkg.abi.MIPT_E_INVALID
+    small = np.zeros((3, 5), dtype=np.uint32)
+    pkg.api.save_bmp(tmp_path / "s.bmp", small)
+    assert (tmp_path / "s.bmp").stat().st_size == 122 + 60
