@@ -633,6 +633,10 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           nd = vecr; renorm = true;  // Ray ctor normalises again (ray.h:11-12)
           shadow_max = r;
           shadow = true;
+          // A terminal vertex the light does not reach (cosine <= 0) has L = 0 whatever the
+          // shadow ray finds, and existsIntersection draws no random numbers: the path ends here
+          // with the radiance the reference computes. The counting variants still cast the ray.
+          if (!STATS && !LIST && Lr == 0.f && Lg == 0.f && Lb == 0.f) { path_done = true; shadow = false; }
           prof.mark(PF_TERMINAL);
         } else if (medium) {
           // isotropic scattering, weight = single-scattering albedo

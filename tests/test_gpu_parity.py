@@ -322,3 +322,22 @@ def test_pair_filter_equals_literal_scan_on_random_quads(api, O, pkg, seed):
     sc.close()
     oidx, ot, opos = O.closest_hit(tris, None, o, d)
     assert np.array_equal(idx, oidx)
+
+
+@pytest.mark.parametrize("scene,fog", [("cornell", 0.0), ("glasscube", 0.0), ("glasscube", 0.3)])
+def test_production_kernel_equals_counting_kernel(api, O, pkg, scene, fog):
+    # the counting variant scans every triangle in index order and casts every shadow ray, like
+    # the reference; the shipped variant filters candidates (pair units, two phases) and ends a
+    # path at a terminal vertex the light cannot reach. Same image, bit for bit.
+    which, glass = SCENES[scene]
+    tris = O.load_test_model(which)
+    W, H, spp = 96, 80, 32
+    cam, light = O.default_camera(W), O.default_light(glass)
+    sc = api.Scene(tris)
+    for rng_mode in (pkg.abi.RNG_MINSTD_PATH, pkg.abi.RNG_COUNTER):
+        plain = sc.render_accumulate(cam, light, O.default_params(W, H, seed=5, rng_mode=rng_mode, fog_sigma_t=fog), 0, spp)
+        counted = sc.render_accumulate(cam, light, O.default_params(W, H, seed=5, rng_mode=rng_mode, fog_sigma_t=fog,
+                                                                    flags=pkg.abi.FLAG_STATS), 0, spp)
+        assert np.array_equal(bits(plain), bits(counted)), rng_mode
+        assert plain.sum() > 0
+    sc.close()
