@@ -366,7 +366,10 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   int x = 0, y = 0;
   uint32_t s = 0, s_end = 0, pixel = 0, pkey = 0;
   size_t list_i = 0;
-  float* dst = nullptr;
+  // State a lane touches only when an item or a path begins or ends is parked in LDS, not in
+  // registers: the item's radiance sum and output slot, the last segment's direction and the
+  // terminal vertex' radiance between the terminal vertex and the end of the path.
+  __shared__ float park[12][BLOCK];
   bool have = false;
   if (LIST) {
     list_i = (size_t)blockIdx.x * BLOCK + tid;
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   uint32_t res_next = 0, res_end = 0, res_base = 0, res_sb = 0, res_tx = 0, res_ty = 0;
   bool drained = LIST;
 
-  float sum_r = 0.f, sum_g = 0.f, sum_b = 0.f;
+  park[0][tid] = 0.f; park[1][tid] = 0.f; park[2][tid] = 0.f;
   uint32_t st[ST_COUNT];
   if (STATS || LIST) {
 #pragma unroll
@@ -391,12 +394,11 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   }
 
   // path state
-  V4 o = {0, 0, 0, 0}, d = {0, 0, 0, 0}, dfin = {0, 0, 0, 0};
+  V4 o = {0, 0, 0, 0}, d = {0, 0, 0, 0};
   Rng rng = {1u, 0u};
   int depth = 0, sp = 0;
   bool shadow = false, fresh = true;
   float shadow_max = 0.f;
-  float Lr = 0.f, Lg = 0.f, Lb = 0.f;  // radiance of the terminal vertex, pending the shadow ray
   uint32_t* tags = lds_stack;
   float* sph_n = reinterpret_cast<float*>(lds_stack + (size_t)P.max_depth * BLOCK);
   const bool fog = P.fog_sigma_t > 0.f;
@@ -466,8 +468,10 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
               s = a.sample_begin + sb * a.item_samples;
               const uint32_t last = a.sample_begin + a.sample_count;
               s_end = (s + a.item_samples < last) ? s + a.item_samples : last;
-              dst = a.partial + ((size_t)sb * ((size_t)W * H) + pixel) * 3;
-              sum_r = 0.f; sum_g = 0.f; sum_b = 0.f;
+              const size_t slot = ((size_t)sb * ((size_t)W * H) + pixel) * 3;  // index into a.partial
+              park[10][tid] = __uint_as_float((uint32_t)slot);
+              park[11][tid] = __uint_as_float((uint32_t)(slot >> 32));
+              park[0][tid] = 0.f; park[1][tid] = 0.f; park[2][tid] = 0.f;
               fresh = true;
               have = true;
             }
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
 
     if (shadow) {
       // light.cpp:26-29: occluded -> zero
-      if (h.idx == 0) { cr = Lr; cg = Lg; cb = Lb; }
+      if (h.idx == 0) { cr = park[7][tid]; cg = park[8][tid]; cb = park[9][tid]; }
       path_done = true;
     } else {
       V4 pos = {0, 0, 0, 0}, nrm = {0, 0, 0, 0};
@@ -603,6 +607,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           lp.z = a.light_pos[2] + (rng_next<RNG_MODE>(rng) * 2.0f - 1.0f) * 0.1f;
           lp.w = a.light_pos[3];
           const V4 at = medium ? o : pos;
+          float Lr, Lg, Lb;
           const V4 v = sub4(lp, at);
           const V4 vecr = normalize4(v);
           const float r = sqrtf(dot4(v, v));
@@ -631,7 +636,8 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
             Lg = (((a.light_col[1] * phase) / den) * tr) * P.fog_albedo;
             Lb = (((a.light_col[2] * phase) / den) * tr) * P.fog_albedo;
           }
-          dfin = d;
+          park[3][tid] = d.x; park[4][tid] = d.y; park[5][tid] = d.z; park[6][tid] = d.w;  // last segment
+          park[7][tid] = Lr; park[8][tid] = Lg; park[9][tid] = Lb;
           nd = vecr; renorm = true;  // Ray ctor normalises again (ray.h:11-12)
           shadow_max = r;
           shadow = true;
@@ -738,6 +744,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
     if (path_done) {
       if (cr != 0.f || cg != 0.f || cb != 0.f) {
         // unwind the recursion, deepest vertex first
+        const V4 dfin = {park[3][tid], park[4][tid], park[5][tid], park[6][tid]};
         for (int k = sp - 1; k >= 0; --k) {
           const uint32_t tag = tags[k * BLOCK + tid];
           if (tag == TAG_GLASS) {  // pathtracer.cpp:62
@@ -757,14 +764,17 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
             cb = (((cb * sv.b) * dn) * 1.0f) * P.diffuse_weight;
           }
         }
-        sum_r += cr; sum_g += cg; sum_b += cb;  // main.cpp:137
+        park[0][tid] += cr; park[1][tid] += cg; park[2][tid] += cb;  // main.cpp:137
       }
       s++;
       fresh = true;
       if (s >= s_end) {
         // the item's samples were added in sample order by this one lane: plain store
         have = false;
-        if (!LIST) { dst[0] = sum_r; dst[1] = sum_g; dst[2] = sum_b; }
+        if (!LIST) {
+          float* dst = a.partial + (((size_t)__float_as_uint(park[11][tid]) << 32) | (size_t)__float_as_uint(park[10][tid]));
+          dst[0] = park[0][tid]; dst[1] = park[1][tid]; dst[2] = park[2][tid];
+        }
       }
     }
     }  // if (ready)
@@ -777,7 +787,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
 
   if (LIST) {
     if (list_i < a.n_paths) {
-      a.rgb[3 * list_i + 0] = sum_r; a.rgb[3 * list_i + 1] = sum_g; a.rgb[3 * list_i + 2] = sum_b;
+      a.rgb[3 * list_i + 0] = park[0][tid]; a.rgb[3 * list_i + 1] = park[1][tid]; a.rgb[3 * list_i + 2] = park[2][tid];
       if (a.counts) { a.counts[2 * list_i] = st[ST_CLOSEST]; a.counts[2 * list_i + 1] = st[ST_SHADOW]; }
     }
   }
