@@ -240,3 +240,47 @@ class Scene:
     def resolve_argb_dev(self, accum, width, height, n_samples, screen):
         _check(self._lib.mipt_resolve_argb_dev(self._h, accum.data_ptr(), width, height, n_samples,
                                                screen.data_ptr(), self._stream()))
+
+
+class Frame:
+    """`pixels` + `samplesSeenSoFar` of the reference's interactive loop (main.cpp:50-56, 98-103),
+    resident on the scene's device: add_samples = Draw's pixel loop, present = its tonemap loop,
+    reset = reset_evolutionModel (utils.cpp:24-32)."""
+
+    def __init__(self, scene, width, height):
+        self._lib = abi.load_library()
+        self.scene, self.width, self.height = scene, width, height
+        h = C.c_void_p()
+        _check(self._lib.mipt_frame_create(scene._h, width, height, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mipt_frame_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def samples(self):
+        return int(self._lib.mipt_frame_samples(self._h))
+
+    def reset(self):
+        _check(self._lib.mipt_frame_reset(self._h))
+
+    def add_samples(self, cam, light, params, n):
+        _check(self._lib.mipt_frame_add_samples(self._h, C.byref(cam), C.byref(light), C.byref(params), n))
+
+    def present(self):
+        screen = np.zeros((self.height, self.width), dtype=np.uint32)
+        _check(self._lib.mipt_frame_present(self._h, _ptr(screen)))
+        return screen
+
+    def read_pixels(self):
+        acc = np.zeros((self.width, self.height, 3), dtype=np.float32)
+        _check(self._lib.mipt_frame_read_pixels(self._h, _ptr(acc)))
+        return acc

@@ -773,6 +773,93 @@ extern "C" int mipt_resolve_argb(MiptScene* s, const float* accum_rgb, int width
   return MIPT_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// progressive frame (device-resident pixels + samplesSeenSoFar)
+
+struct MiptFrame {
+  MiptScene* scene = nullptr;
+  int width = 0, height = 0;
+  uint32_t samples = 0;
+  float* d_accum = nullptr;
+  uint32_t* d_screen = nullptr;
+  hipStream_t stream = nullptr;
+};
+
+extern "C" void mipt_frame_destroy(MiptFrame* f) {
+  if (!f) return;
+  (void)hipSetDevice(f->scene->device);
+  if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
+  if (f->d_accum) (void)hipFree(f->d_accum);
+  if (f->d_screen) (void)hipFree(f->d_screen);
+  delete f;
+}
+
+static int frame_create_impl(MiptFrame* f) {
+  const size_t n = (size_t)f->width * f->height;
+  HIP_TRY(hipSetDevice(f->scene->device));
+  HIP_TRY(hipStreamCreate(&f->stream));
+  HIP_TRY(hipMalloc(&f->d_accum, n * 12));
+  HIP_TRY(hipMalloc(&f->d_screen, n * 4));
+  HIP_TRY(hipMemsetAsync(f->d_accum, 0, n * 12, f->stream));
+  return MIPT_OK;
+}
+
+extern "C" int mipt_frame_create(MiptScene* scene, int width, int height, MiptFrame** out) {
+  if (!out) return fail(MIPT_E_INVALID, "mipt_frame_create: out is null");
+  *out = nullptr;
+  if (!scene) return fail(MIPT_E_INVALID, "mipt_frame_create: scene is null");
+  if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
+    return fail(MIPT_E_INVALID, "mipt_frame_create: image size %d x %d out of range", width, height);
+  MiptFrame* f = new (std::nothrow) MiptFrame();
+  if (!f) return fail(MIPT_E_NOMEM, "mipt_frame_create: host allocation failed");
+  f->scene = scene; f->width = width; f->height = height;
+  const int rc = frame_create_impl(f);
+  if (rc != MIPT_OK) { mipt_frame_destroy(f); return rc; }
+  *out = f;
+  return MIPT_OK;
+}
+
+extern "C" int mipt_frame_reset(MiptFrame* f) {
+  if (!f) return fail(MIPT_E_INVALID, "mipt_frame_reset: frame is null");
+  HIP_TRY(hipSetDevice(f->scene->device));
+  HIP_TRY(hipMemsetAsync(f->d_accum, 0, (size_t)f->width * f->height * 12, f->stream));
+  f->samples = 0;
+  return MIPT_OK;
+}
+
+extern "C" int mipt_frame_add_samples(MiptFrame* f, const MiptCamera* cam, const MiptLight* light,
+                                      const MiptParams* params, uint32_t n_samples) {
+  if (!f || !params) return fail(MIPT_E_INVALID, "mipt_frame_add_samples: null argument");
+  if (n_samples == 0) return MIPT_OK;
+  if ((uint64_t)f->samples + n_samples > 0x7FFFFFFFull)
+    return fail(MIPT_E_INVALID, "mipt_frame_add_samples: sample count exceeds int range");
+  MiptParams p = *params;
+  p.width = f->width; p.height = f->height;
+  const int rc = mipt_render_accumulate_dev(f->scene, cam, light, &p, f->samples, n_samples, f->d_accum, f->stream);
+  if (rc != MIPT_OK) return rc;
+  f->samples += n_samples;
+  return MIPT_OK;
+}
+
+extern "C" int mipt_frame_present(MiptFrame* f, uint32_t* screen_buffer) {
+  if (!f || !screen_buffer) return fail(MIPT_E_INVALID, "mipt_frame_present: null argument");
+  const int rc = mipt_resolve_argb_dev(f->scene, f->d_accum, f->width, f->height, f->samples, f->d_screen, f->stream);
+  if (rc != MIPT_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(screen_buffer, f->d_screen, (size_t)f->width * f->height * 4, hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  return MIPT_OK;
+}
+
+extern "C" int mipt_frame_read_pixels(MiptFrame* f, float* accum_rgb) {
+  if (!f || !accum_rgb) return fail(MIPT_E_INVALID, "mipt_frame_read_pixels: null argument");
+  HIP_TRY(hipSetDevice(f->scene->device));
+  HIP_TRY(hipMemcpyAsync(accum_rgb, f->d_accum, (size_t)f->width * f->height * 12, hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  return MIPT_OK;
+}
+
+extern "C" int mipt_frame_samples(const MiptFrame* f) { return f ? (int)f->samples : 0; }
+
 extern "C" int mipt_debug_selfcheck(MiptScene* s, uint64_t n_rays, uint32_t seed, uint64_t out[8]) {
   if (!s || !out) return fail(MIPT_E_INVALID, "mipt_debug_selfcheck: null argument");
   if (n_rays > ((uint64_t)1 << 36)) return fail(MIPT_E_INVALID, "mipt_debug_selfcheck: at most 2^36 rays per call");

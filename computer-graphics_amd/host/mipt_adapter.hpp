@@ -173,6 +173,39 @@ inline void Draw(GpuScene& gpu, ScreenT* screen, const CameraT& cam, const Light
   check(mipt_resolve_argb(gpu.handle(), accum.data(), W, H, (uint32_t)samplesSeenSoFar, screen->buffer));
 }
 
+// The interactive loop of main.cpp:98-103 with the image kept on the device: `pixels` and
+// `samplesSeenSoFar` become one Frame; only the ARGB screen crosses PCIe per frame.
+//     mipt_host::Frame frame(*gpu, SCREEN_WIDTH, SCREEN_HEIGHT);
+//     while (NoQuitMessageSDL()) {
+//       if (handleKeyboard(...changed camera or light...)) frame.reset();   // reset_evolutionModel
+//       frame.add_samples(cam, light, 16);                                   // Draw's pixel loop
+//       frame.present(screen);                                               // Draw's tonemap loop
+//       SDL_Renderframe(screen);
+//     }
+class Frame {
+ public:
+  Frame(GpuScene& gpu, int width, int height) : gpu_(gpu) {
+    check(mipt_frame_create(gpu.handle(), width, height, &f_));
+    if (!gpu.params_set) { mipt_params_default(&gpu.params, width, height); gpu.params_set = true; }
+  }
+  ~Frame() { mipt_frame_destroy(f_); }
+  Frame(const Frame&) = delete;
+  Frame& operator=(const Frame&) = delete;
+  void reset() { check(mipt_frame_reset(f_)); }
+  template <class CameraT, class LightT>
+  void add_samples(const CameraT& cam, const LightT& light, int n) {
+    const MiptCamera c = to_mipt_camera(cam);
+    const MiptLight l = to_mipt_light(light);
+    check(mipt_frame_add_samples(f_, &c, &l, &gpu_.params, (uint32_t)n));
+  }
+  template <class ScreenT> void present(ScreenT* screen) { check(mipt_frame_present(f_, screen->buffer)); }
+  int samplesSeenSoFar() const { return mipt_frame_samples(f_); }
+
+ private:
+  GpuScene& gpu_;
+  MiptFrame* f_ = nullptr;
+};
+
 // SDL_SaveImage (SDLauxiliary.h:25-54) for the reference's `screen` struct (buffer, width, height)
 template <class ScreenT>
 inline void SDL_SaveImage(ScreenT* s, const char* filename) {

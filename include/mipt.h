@@ -245,6 +245,27 @@ int mipt_render_accumulate_dev(MiptScene* scene, const MiptCamera* cam, const Mi
 int mipt_resolve_argb_dev(MiptScene* scene, const float* d_accum_rgb, int width, int height,
                           uint32_t n_samples, uint32_t* d_screen_buffer, void* stream);
 
+/* Progressive rendering with the image resident on the device: `vec3** pixels` + `samplesSeenSoFar`
+ * (main.cpp:50-56) as one object, so that a frame of the interactive loop (main.cpp:98-103) moves
+ * only the ARGB screen over PCIe.
+ *   mipt_frame_reset        reset_evolutionModel (utils.cpp:24-32): what handleKeyboard calls when
+ *                           the camera or the light moved
+ *   mipt_frame_add_samples  Draw's pixel loop (main.cpp:121-139) for n more samples of every pixel,
+ *                           continuing the sample index; asynchronous (the frame's own stream)
+ *   mipt_frame_present      Draw's tonemap loop (main.cpp:141-145) into the host screen buffer; waits
+ *                           for the samples added so far
+ *   mipt_frame_read_pixels  the accumulated sums, x-major W*H*3 floats (the reference's `pixels`)
+ * The frame uses its scene's scratch memory: one host thread per scene, as for the other calls. */
+typedef struct MiptFrame MiptFrame;
+int mipt_frame_create(MiptScene* scene, int width, int height, MiptFrame** out);
+void mipt_frame_destroy(MiptFrame* frame);
+int mipt_frame_reset(MiptFrame* frame);
+int mipt_frame_add_samples(MiptFrame* frame, const MiptCamera* cam, const MiptLight* light,
+                           const MiptParams* params, uint32_t n_samples);
+int mipt_frame_present(MiptFrame* frame, uint32_t* screen_buffer);
+int mipt_frame_read_pixels(MiptFrame* frame, float* accum_rgb);
+int mipt_frame_samples(const MiptFrame* frame); /* samplesSeenSoFar */
+
 /* Counters of the most recent render / trace call made with MIPT_FLAG_STATS, and
  * the device time of its path kernel (measured with HIP events on the launch
  * stream; synchronises that stream). */

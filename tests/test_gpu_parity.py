@@ -341,3 +341,33 @@ def test_production_kernel_equals_counting_kernel(api, O, pkg, scene, fog):
         assert np.array_equal(bits(plain), bits(counted)), rng_mode
         assert plain.sum() > 0
     sc.close()
+
+
+def test_progressive_frame_equals_host_round_trips(api, O):
+    # pixels + samplesSeenSoFar resident on the device: same sums and the same ARGB screen as
+    # render_accumulate / resolve_argb through host buffers; reset starts over
+    tris = O.load_test_model(2)
+    W, H = 72, 56
+    cam, light = O.default_camera(W), O.default_light(True)
+    p = O.default_params(W, H, seed=11, fog_sigma_t=0.2)
+    sc = api.Scene(tris)
+    fr = api.Frame(sc, W, H)
+    for n in (1, 4, 7):
+        fr.add_samples(cam, light, p, n)
+    assert fr.samples == 12
+    screen = fr.present()
+    pixels = fr.read_pixels()
+    acc = None
+    begin = 0
+    for n in (1, 4, 7):
+        acc = sc.render_accumulate(cam, light, p, begin, n, accum=acc)
+        begin += n
+    assert np.array_equal(bits(pixels), bits(acc))
+    assert np.array_equal(screen, sc.resolve_argb(acc, 12))
+    fr.reset()
+    assert fr.samples == 0 and not fr.read_pixels().any()
+    fr.add_samples(cam, light, p, 12)
+    whole = fr.read_pixels()
+    assert np.allclose(whole, acc, rtol=2e-6, atol=1e-7)   # one call of 12 = 1 + 4 + 7 up to the order of the sums
+    fr.close()
+    sc.close()
