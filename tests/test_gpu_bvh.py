@@ -161,3 +161,30 @@ def test_glasswolf_paths_match_oracle(api, O, pkg):
     assert st.glass_bounces > 100
     same = (bits(img) == bits(ref)).all(axis=2).mean()
     assert same > 0.99, same
+
+
+def test_tree_scene_with_sphere_and_all_materials(api, O, dtype):
+    # closestIntersection's second loop (spheres, intersections.cpp:39-52) after a tree walk, and
+    # diffuse / mirror / glass / specular triangles in one scene
+    tris = np.concatenate([bigscenes.room(O), bigscenes.soup(dtype, 3000, seed=8, size=0.08)])
+    sph = api.make_sphere(0.3, [-0.45, 0.7, -0.55, 1], [1, 0, 0])
+    sc = api.Scene(tris, sph)
+    assert sc.bvh_info()[0]
+    n = 1 << 13
+    for o, d in (raygen.primary_rays(n), raygen.interior_rays(n)):
+        idx, t, pos = sc.closest_hit(o, d)
+        oidx, ot, opos = O.closest_hit(tris, sph, o, d)
+        assert np.array_equal(idx, oidx)
+        hit = oidx >= 0
+        assert np.array_equal(bits(t[hit]), bits(ot[hit])) and np.array_equal(bits(pos[hit]), bits(opos[hit]))
+    assert (idx == len(tris)).sum() > 20
+    W = H = 24
+    cam, light = api.default_camera(W), api.default_light(True)
+    p = api.default_params(W, H, flags=1, seed=2)
+    img = sc.render_accumulate(cam, light, p, 0, 4)
+    st = sc.stats()
+    sc.close()
+    ref, ost = O.render_accumulate(tris, sph, cam, light, p, 0, 4)
+    for k in ("closest_rays", "shadow_rays", "diffuse_bounces", "mirror_bounces", "glass_bounces", "sphere_tests"):
+        assert getattr(st, k) == getattr(ost, k), k
+    assert (bits(img) == bits(ref)).all(axis=2).mean() > 0.99
