@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <iterator>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -60,6 +61,8 @@ struct MiptScene {
   float* d_partial = nullptr;
   size_t partial_bytes = 0;
   BvhNode* d_bvh = nullptr;
+  int* d_big = nullptr;
+  int n_tree_tris = 0;
   double bvh_build_ms = 0.0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -78,6 +81,7 @@ static void scene_free(MiptScene* s) {
   if (s->d_queue) (void)hipFree(s->d_queue);
   if (s->d_partial) (void)hipFree(s->d_partial);
   if (s->d_bvh) (void)hipFree(s->d_bvh);
+  if (s->d_big) (void)hipFree(s->d_big);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -95,11 +99,15 @@ struct DevBuf {
 
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
-// LBVH over s->d_tris (n >= 2): bounds -> Morton keys -> radix sort -> topology -> refit waves.
-// Everything runs on the null stream of the scene's device; the tree is final on return.
-static int build_bvh(MiptScene* s, int n) {
-  DevBuf box, cen, scene, keys, ids, keys2, ids2, node_box, ready, done, tmp;
-  HIP_TRY(box.alloc((size_t)n * sizeof(Aabb)));
+// LBVH over the triangles listed in `subset` (n >= 2 of them): bounds -> Morton keys -> radix sort
+// -> topology -> refit waves. Everything runs on the null stream of the scene's device; the tree
+// is final on return.
+static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
+  const int n = (int)subset.size();
+  DevBuf box, cen, scene, keys, ids, keys2, ids2, node_box, ready, done, tmp, sub;
+  HIP_TRY(sub.alloc((size_t)n * 4));
+  HIP_TRY(hipMemcpy(sub.p, subset.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(box.alloc((size_t)s->d.n_tris * sizeof(Aabb)));
   HIP_TRY(cen.alloc((size_t)n * 12));
   HIP_TRY(scene.alloc(6 * 4));
   HIP_TRY(keys.alloc((size_t)n * 8)); HIP_TRY(keys2.alloc((size_t)n * 8));
@@ -113,10 +121,10 @@ static int build_bvh(MiptScene* s, int n) {
   HIP_TRY(hipEventRecord(e0, nullptr));
   const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
   HIP_TRY(hipMemcpy(scene.p, init, sizeof init, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_bvh_bounds, dim3(grid_for(n)), dim3(BLOCK), 0, nullptr, s->d_tris, n, box.as<Aabb>(),
-                     cen.as<float>(), scene.as<uint32_t>());
+  hipLaunchKernelGGL(k_bvh_bounds, dim3(grid_for(n)), dim3(BLOCK), 0, nullptr, s->d_tris, sub.as<int>(), n,
+                     box.as<Aabb>(), cen.as<float>(), scene.as<uint32_t>());
   hipLaunchKernelGGL(k_bvh_morton, dim3(grid_for(n)), dim3(BLOCK), 0, nullptr, cen.as<float>(), n,
-                     scene.as<uint32_t>(), keys.as<unsigned long long>(), ids.as<int>());
+                     scene.as<uint32_t>(), sub.as<int>(), keys.as<unsigned long long>(), ids.as<int>());
   HIP_TRY(hipGetLastError());
   size_t tmp_bytes = 0;
   HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<unsigned long long>(), keys2.as<unsigned long long>(),
@@ -151,6 +159,57 @@ static int build_bvh(MiptScene* s, int n) {
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   s->bvh_build_ms = ms;
   s->d.bvh = s->d_bvh;
+  s->d.bvh_root = 0;
+  return MIPT_OK;
+}
+
+// Tree scenes: which triangles stay out of the tree. A triangle whose extent exceeds 1/8 of the
+// scene's (a wall of the room around a mesh) would put its box around every node above it;
+// up to MAX_BIG such triangles are tested one by one before the walk instead.
+constexpr size_t MAX_BIG = 64;
+static int build_tree_scene(MiptScene* s, const MiptTriangle* tris, size_t n_tris) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  std::vector<float> extent(n_tris);
+  for (size_t i = 0; i < n_tris; ++i) {
+    const float* v[3] = {tris[i].v0, tris[i].v1, tris[i].v2};
+    float e = 0.f;
+    for (int k = 0; k < 3; ++k) {
+      const float a = std::fmin(v[0][k], std::fmin(v[1][k], v[2][k])), b = std::fmax(v[0][k], std::fmax(v[1][k], v[2][k]));
+      if (a < lo[k]) lo[k] = a;
+      if (b > hi[k]) hi[k] = b;
+      e = std::fmax(e, b - a);
+    }
+    extent[i] = e;  // NaN vertices give NaN or 0 here: never "big", they stay in the tree
+  }
+  const float scene_extent = std::fmax(hi[0] - lo[0], std::fmax(hi[1] - lo[1], hi[2] - lo[2]));
+  std::vector<int> big, small;
+  for (size_t i = 0; i < n_tris; ++i) (extent[i] > 0.125f * scene_extent ? big : small).push_back((int)i);
+  if (big.size() > MAX_BIG) {  // keep the largest, in index order; the rest go into the tree after all
+    std::vector<int> by_size = big;
+    std::sort(by_size.begin(), by_size.end(), [&](int a, int b) { return extent[a] > extent[b] || (extent[a] == extent[b] && a < b); });
+    by_size.resize(MAX_BIG);
+    std::sort(by_size.begin(), by_size.end());
+    std::vector<int> rest;
+    std::set_difference(big.begin(), big.end(), by_size.begin(), by_size.end(), std::back_inserter(rest));
+    small.insert(small.end(), rest.begin(), rest.end());
+    std::sort(small.begin(), small.end());
+    big = by_size;
+  }
+  const char* no_big = getenv("MIPT_NO_BIG_LIST");  // developer switch: every triangle in the tree
+  if (no_big && no_big[0] == '1') { small.insert(small.end(), big.begin(), big.end()); std::sort(small.begin(), small.end()); big.clear(); }
+  s->n_tree_tris = (int)small.size();
+  if (!big.empty()) {
+    HIP_TRY(hipMalloc(&s->d_big, big.size() * 4));
+    HIP_TRY(hipMemcpy(s->d_big, big.data(), big.size() * 4, hipMemcpyHostToDevice));
+  }
+  s->d.big_ids = s->d_big;
+  s->d.n_big = (int)big.size();
+  if (small.size() >= 2) return build_bvh(s, small);
+  // zero or one triangle left: no inner node, the scene still counts as a tree scene
+  HIP_TRY(hipMalloc(&s->d_bvh, sizeof(BvhNode)));
+  HIP_TRY(hipMemset(s->d_bvh, 0, sizeof(BvhNode)));
+  s->d.bvh = s->d_bvh;
+  s->d.bvh_root = small.empty() ? BVH_DONE : -1 - small[0];
   return MIPT_OK;
 }
 
@@ -341,7 +400,7 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
   s->d.n_spheres = (int)n_spheres;
   s->d.scale = scale;
   const char* no_bvh = getenv("MIPT_NO_BVH");  // developer switch: always scan linearly
-  if (n_tris >= MIPT_BVH_MIN_TRIS && !(no_bvh && no_bvh[0] == '1')) return build_bvh(s, (int)n_tris);
+  if (n_tris >= MIPT_BVH_MIN_TRIS && !(no_bvh && no_bvh[0] == '1')) return build_tree_scene(s, tris, n_tris);
   std::vector<ScanUnit> units;
   build_scan_units(tris, tr, n_tris, units, s->n_pair_units);
   HIP_TRY(hipMalloc(&s->d_units, units.size() * sizeof(ScanUnit)));
@@ -384,7 +443,7 @@ extern "C" int mipt_scene_has_bvh(MiptScene* s, uint64_t* n_nodes, double* build
   if (n_nodes) *n_nodes = 0;
   if (build_ms) *build_ms = 0.0;
   if (!s || !s->d.bvh) return 0;
-  if (n_nodes) *n_nodes = (uint64_t)(s->d.n_tris - 1);
+  if (n_nodes) *n_nodes = (uint64_t)(s->n_tree_tris > 1 ? s->n_tree_tris - 1 : 0);
   if (build_ms) *build_ms = s->bvh_build_ms;
   return 1;
 }
@@ -723,6 +782,10 @@ extern "C" int mipt_get_stats(MiptScene* s, MiptStats* out) {
     fprintf(stderr, " (total %.3g ticks); candidates per query %.2f, phase-2 rounds per wave query %.2f\n", tot,
             (double)pf[PF_N_CANDS] / (double)(pf[PF_N_QUERIES] ? pf[PF_N_QUERIES] : 1),
             64.0 * (double)pf[PF_N_ROUNDS] / (double)(pf[PF_N_QUERIES] ? pf[PF_N_QUERIES] : 1));
+    fprintf(stderr, "[mipt sections] queries with >= 3 / 4 / 6 candidates: %.2f %% / %.2f %% / %.3f %%\n",
+            100.0 * (double)pf[PF_N_GE3] / (double)(pf[PF_N_QUERIES] ? pf[PF_N_QUERIES] : 1),
+            100.0 * (double)pf[PF_N_GE4] / (double)(pf[PF_N_QUERIES] ? pf[PF_N_QUERIES] : 1),
+            100.0 * (double)pf[PF_N_GE6] / (double)(pf[PF_N_QUERIES] ? pf[PF_N_QUERIES] : 1));
   }
 #endif
   if (s->stats_valid) {

@@ -67,11 +67,14 @@ __host__ __device__ inline float float_unflip(uint32_t u) {
 }
 
 // per triangle: padded bounds; scene bounds of the centroids by atomics on flipped floats
-__global__ __launch_bounds__(BLOCK) void k_bvh_bounds(const TriRec* __restrict__ tris, int n, Aabb* __restrict__ box,
-                                                      float* __restrict__ centroid, uint32_t* __restrict__ scene) {
+// `subset` lists the triangles that go into the tree; box is indexed by triangle, centroid by position
+__global__ __launch_bounds__(BLOCK) void k_bvh_bounds(const TriRec* __restrict__ tris, const int* __restrict__ subset,
+                                                      int n, Aabb* __restrict__ box, float* __restrict__ centroid,
+                                                      uint32_t* __restrict__ scene) {
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
-  const TriRec T = tris[i];
+  const int tri = subset[i];
+  const TriRec T = tris[tri];
   const float v0[3] = {T.v0x, T.v0y, T.v0z};
   const float e1[3] = {T.e1x, T.e1y, T.e1z}, e2[3] = {T.e2x, T.e2y, T.e2z};
   Aabb b;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_bounds(const TriRec* __restrict__
     b.lo[k] -= pad;
     b.hi[k] += pad;
   }
-  box[i] = b;
+  box[tri] = b;
 }
 
 __device__ __forceinline__ unsigned long long spread21(unsigned long long v) {  // 21 bits -> every third bit
@@ -106,6 +109,7 @@ __device__ __forceinline__ unsigned long long spread21(unsigned long long v) {  
 
 __global__ __launch_bounds__(BLOCK) void k_bvh_morton(const float* __restrict__ centroid, int n,
                                                       const uint32_t* __restrict__ scene,
+                                                      const int* __restrict__ subset,
                                                       unsigned long long* __restrict__ keys, int* __restrict__ ids) {
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_morton(const float* __restrict__ 
     code |= spread21(q) << k;
   }
   keys[i] = code;
-  ids[i] = i;
+  ids[i] = subset[i];
 }
 
 // common-prefix length of sorted keys i and j; equal keys are told apart by their position
@@ -300,14 +304,51 @@ struct BvhMem {
   BvhHit list[BVH_LIST];  // closest: surviving hits, sorted by triangle index
 };
 
-__device__ __forceinline__ void bvh_begin(BvhTrav& T, const DeviceScene& sc, const BvhRay& r, bool shadow,
+// A triangle the reference's test could accept (bvh_leaf returned true) enters the walk's state.
+__device__ __forceinline__ void bvh_take(BvhTrav& T, BvhMem& M, const BvhRay& r, bool shadow, float max_t, int i,
+                                         float t, float z, float x1, float x2) {
+  if (shadow) {
+    if (t <= max_t && (x1 + x2) <= 1.0f) { T.hit = true; T.cur = BVH_DONE; }  // intersections.cpp:75-77
+    return;
+  }
+  if (!(fabsf(t - z) <= 0.000244140625f * z + r.delta)) { T.redo = true; T.cur = BVH_DONE; }  // 2^-12
+  if (z < T.zmin) {
+    T.zmin = z;
+    T.bound = T.zmin * BVH_BAND + 4.0f * r.delta;
+    int w = 0;  // drop hits that fell out of the band
+    for (int k = 0; k < T.n_list; ++k)
+      if (M.list[k].t <= T.bound) M.list[w++] = M.list[k];
+    T.n_list = w;
+  }
+  if (t <= T.bound) {
+    if (T.n_list == BVH_LIST) {
+      T.redo = true; T.cur = BVH_DONE;
+    } else {
+      int k = T.n_list++;
+      while (k > 0 && M.list[k - 1].idx > i) { M.list[k] = M.list[k - 1]; --k; }  // keep index order
+      M.list[k] = {i, t, z, x1, x2};
+    }
+  }
+}
+
+__device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, const DeviceScene& sc, BvhRay& r, bool shadow,
                                           float max_t) {
-  T.cur = sc.n_tris > 1 ? 0 : -1;  // a single triangle is its own tree
+  T.cur = sc.bvh_root;
   T.sp = 0; T.n_list = 0;
   T.zmin = 3.402823466e+38f;
   // any-hit: t of an accepted triangle is <= max_t; its true distance can exceed that by the filter's slack
   T.bound = shadow ? fabsf(max_t) * 1.05f + 4.0f * r.delta + 1e-30f : 3.402823466e+38f;
   T.redo = false; T.hit = false;
+  // The triangles too large for the tree first (wave-uniform loop): a wall spans the scene, its
+  // box would swallow every ray; tested up front it also gives the walk its first pruning bound.
+  for (int b = 0; b < sc.n_big && !(T.redo || T.hit); ++b) {
+    const int i = sc.big_ids[b];
+    float t, z, x1, x2;
+    r.n_leaves++;
+    if (bvh_leaf(sc, r, i, t, z, x1, x2)) bvh_take(T, M, r, shadow, max_t, i, t, z, x1, x2);
+  }
+  // a big triangle may have ended the query (any-hit found, or redo) before the tree had a say
+  T.cur = (T.redo || T.hit) ? BVH_DONE : sc.bvh_root;
 }
 
 // "while-while": all walking lanes step through inner nodes until each holds a leaf (or is done),
@@ -343,28 +384,7 @@ __device__ __forceinline__ void bvh_burst(BvhTrav& T, BvhMem& M, const DeviceSce
       r.n_leaves++;
       T.cur = T.sp ? M.stack[--T.sp] : BVH_DONE;
       if (bvh_leaf(sc, r, i, t, z, x1, x2)) {
-        if (shadow) {
-          if (t <= max_t && (x1 + x2) <= 1.0f) { T.hit = true; T.cur = BVH_DONE; }  // intersections.cpp:75-77
-        } else {
-          if (!(fabsf(t - z) <= 0.000244140625f * z + r.delta)) { T.redo = true; T.cur = BVH_DONE; }  // 2^-12
-          if (z < T.zmin) {
-            T.zmin = z;
-            T.bound = T.zmin * BVH_BAND + 4.0f * r.delta;
-            int w = 0;  // drop hits that fell out of the band
-            for (int k = 0; k < T.n_list; ++k)
-              if (M.list[k].t <= T.bound) M.list[w++] = M.list[k];
-            T.n_list = w;
-          }
-          if (t <= T.bound) {
-            if (T.n_list == BVH_LIST) {
-              T.redo = true; T.cur = BVH_DONE;
-            } else {
-              int k = T.n_list++;
-              while (k > 0 && M.list[k - 1].idx > i) { M.list[k] = M.list[k - 1]; --k; }  // keep index order
-              M.list[k] = {i, t, z, x1, x2};
-            }
-          }
-        }
+        bvh_take(T, M, r, shadow, max_t, i, t, z, x1, x2);
       }
     }
     // lanes still walking (this ballot is taken by the lanes inside the loop only)
@@ -400,8 +420,16 @@ __device__ __forceinline__ void bvh_closest_exhaustive(const DeviceScene& sc, co
     float bz = 0.f, b1 = 0.f, b2 = 0.f;
     int stack[BVH_STACK];
     int sp = 0;
-    int cur = sc.n_tris > 1 ? 0 : -1;
+    for (int b = 0; b < sc.n_big; ++b) {
+      const int i = sc.big_ids[b];
+      float t, z, x1, x2;
+      if (i > after && i < best && bvh_leaf(sc, r, i, t, z, x1, x2) && t <= h.lim) {
+        best = i; bz = z; b1 = x1; b2 = x2;
+      }
+    }
+    int cur = sc.bvh_root;
     for (;;) {
+      if (cur == BVH_DONE) break;
       if (cur < 0) {
         const int i = -1 - cur;
         float t, z, x1, x2;

@@ -81,7 +81,10 @@ struct __attribute__((aligned(64))) ScanUnit {
 struct BvhNode;
 
 struct DeviceScene {
-  const BvhNode* bvh;  // LBVH over the triangles, or null: linear scan
+  const BvhNode* bvh;  // LBVH over the small triangles, or null: linear scan
+  const int* big_ids;  // tree scenes: triangles too large for the tree (walls), tested one by one
+  int n_big;
+  int bvh_root;        // 0 = inner root, -1 - i = the tree is the single triangle i, BVH_DONE = empty
   const ScanUnit* units;  // phase-1 records of the linear scan (null with an LBVH)
   const TriRec* tris;
   const ShadeRec* shade;  // n_tris triangle records followed by n_spheres sphere records

@@ -63,7 +63,7 @@ struct PathArgs {
 // the previous mark to the section's LDS counter; mipt_get_stats prints the totals.
 enum ProfSection {
   PF_QUEUE = 0, PF_RAYGEN, PF_PHASE1, PF_PHASE2, PF_HIT, PF_TERMINAL, PF_SCATTER, PF_DIFFUSE, PF_MIRROR,
-  PF_GLASS, PF_RENORM, PF_UNWIND, PF_N_QUERIES, PF_N_CANDS, PF_N_ROUNDS, PF_COUNT
+  PF_GLASS, PF_RENORM, PF_UNWIND, PF_N_QUERIES, PF_N_CANDS, PF_N_ROUNDS, PF_N_GE3, PF_N_GE4, PF_N_GE6, PF_COUNT
 };
 #ifdef MIPT_PROFILE_SECTIONS
 struct Prof {
@@ -143,6 +143,9 @@ __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d
     prof.mark(PF_PHASE1);
     prof.count(PF_N_QUERIES, 1u);
     prof.count(PF_N_CANDS, (uint32_t)__popc(mask));
+    prof.count(PF_N_GE3, __popc(mask) >= 3 ? 1u : 0u);
+    prof.count(PF_N_GE4, __popc(mask) >= 4 ? 1u : 0u);
+    prof.count(PF_N_GE6, __popc(mask) >= 6 ? 1u : 0u);
     while (__any(mask != 0)) {
       prof.count_wave(PF_N_ROUNDS);
       if (mask != 0) {
@@ -176,7 +179,7 @@ __device__ __forceinline__ void scene_query(const DeviceScene& sc, V4 o, V4 d, b
   BvhRay r = bvh_ray(sc, o, d);
   BvhTrav T;
   BvhMem M;
-  bvh_begin(T, sc, r, shadow, h.lim);
+  bvh_begin(T, M, sc, r, shadow, h.lim);
   while (T.cur != BVH_DONE) bvh_burst(T, M, sc, sc.bvh, r, shadow, h.lim, overflow);
   if (T.redo) {
     redo++;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_batch(DeviceScene sc, const float
         const float4 of = origin[my], df = dir[my];
         r = bvh_ray(sc, {of.x, of.y, of.z, of.w}, {df.x, df.y, df.z, df.w});
         lim0 = SHADOW ? max_t[my] : 3.402823466e+38f;
-        bvh_begin(T, sc, r, SHADOW, lim0);
+        bvh_begin(T, M, sc, r, SHADOW, lim0);
         have = true;
       }
     }
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
     const float lim0 = shadow ? shadow_max : 3.402823466e+38f;
     if (BVH) {
       BvhRay r = bvh_ray(a.sc, o, d);  // o, d stay put while the lane walks
-      if (!walking) { bvh_begin(trav, a.sc, r, shadow, lim0); walking = true; }
+      if (!walking) { bvh_begin(trav, trav_mem, a.sc, r, shadow, lim0); walking = true; }
       bvh_burst(trav, trav_mem, a.sc, a.sc.bvh, r, shadow, lim0, overflow);
       n_tests = r.n_leaves; n_nodes = r.n_nodes;
       if (trav.cur == BVH_DONE) {
