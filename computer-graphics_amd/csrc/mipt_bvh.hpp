@@ -225,7 +225,10 @@ struct BvhHit { int idx; float t, z, by, bz; };
 
 // A tree over sorted 63-bit keys, equal keys split by their 32-bit position, is at most 95 levels
 // deep, and the traversal pushes at most one entry per level: the stack cannot overflow.
-constexpr int BVH_STACK = 96;
+#ifndef MIPT_BVH_STACK
+#define MIPT_BVH_STACK 96
+#endif
+constexpr int BVH_STACK = MIPT_BVH_STACK;
 // a burst of the walk ends when fewer than KEEP_NUM / KEEP_DEN of the lanes that entered it still walk
 #ifndef MIPT_BVH_KEEP_NUM
 #define MIPT_BVH_KEEP_NUM 1
