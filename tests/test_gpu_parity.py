@@ -371,3 +371,25 @@ def test_progressive_frame_equals_host_round_trips(api, O):
     assert np.allclose(whole, acc, rtol=2e-6, atol=1e-7)   # one call of 12 = 1 + 4 + 7 up to the order of the sums
     fr.close()
     sc.close()
+
+
+@pytest.mark.parametrize("with_sphere", [False, True])
+def test_maximum_depth_long_paths(api, O, pkg, with_sphere):
+    # MIPT_MAX_DEPTH_LIMIT levels with Russian roulette nearly off: the per-lane vertex stack (and
+    # the sphere normals beside it) at its largest, every path many bounces long
+    tris = O.load_test_model(2)
+    sph = api.make_sphere(0.3, [-0.45, 0.7, -0.55, 1], [1, 0, 0]) if with_sphere else None
+    W = H = 32
+    cam, light = O.default_camera(W), O.default_light(True)
+    p = O.default_params(W, H, max_depth=16, rr_prob=0.02, flags=pkg.abi.FLAG_STATS, seed=4)
+    sc = api.Scene(tris, sph)
+    img = sc.render_accumulate(cam, light, p, 0, 4)
+    st = sc.stats()
+    sc.close()
+    ref, ost = O.render_accumulate(tris, sph, cam, light, p, 0, 4)
+    assert (st.closest_rays, st.shadow_rays) == (ost.closest_rays, ost.shadow_rays)
+    assert st.closest_rays > 5 * W * H * 4
+    assert (bits(img) == bits(ref)).all(axis=2).mean() > 0.995
+    p.max_depth = 17
+    with pytest.raises(api.MiptError):
+        api.Scene(tris).render_accumulate(cam, light, p, 0, 1)
