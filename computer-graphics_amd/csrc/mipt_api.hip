@@ -116,8 +116,12 @@ static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
   HIP_TRY(ready.alloc((size_t)n * 2));
   HIP_TRY(done.alloc(4));
   HIP_TRY(hipMalloc(&s->d_bvh, (size_t)(n - 1) * sizeof(BvhNode)));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  struct Events {  // destroyed on every return path
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b));
+  hipEvent_t e0 = ev.a, e1 = ev.b;
   HIP_TRY(hipEventRecord(e0, nullptr));
   const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
   HIP_TRY(hipMemcpy(scene.p, init, sizeof init, hipMemcpyHostToDevice));
@@ -156,7 +160,6 @@ static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   s->bvh_build_ms = ms;
   s->d.bvh = s->d_bvh;
   s->d.bvh_root = 0;
