@@ -170,7 +170,10 @@ static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
 // scene's (a wall of the room around a mesh) would put its box around every node above it;
 // up to MAX_BIG such triangles are tested one by one before the walk instead.
 constexpr size_t MAX_BIG = 64;
-static int build_tree_scene(MiptScene* s, const MiptTriangle* tris, size_t n_tris) {
+static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>& tr, const std::vector<int>& ids,
+                             std::vector<ScanUnit>& units, uint32_t& n_pair_units);
+static int upload_scan_units(MiptScene* s, const std::vector<ScanUnit>& units);
+static int build_tree_scene(MiptScene* s, const MiptTriangle* tris, const std::vector<TriRec>& tr, size_t n_tris) {
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   std::vector<float> extent(n_tris);
   for (size_t i = 0; i < n_tris; ++i) {
@@ -207,6 +210,12 @@ static int build_tree_scene(MiptScene* s, const MiptTriangle* tris, size_t n_tri
   }
   s->d.big_ids = s->d_big;
   s->d.n_big = (int)big.size();
+  if (!big.empty()) {  // the candidate filter's units over the big list (walls come in coplanar pairs)
+    std::vector<ScanUnit> units;
+    build_scan_units(tris, tr, big, units, s->n_pair_units);
+    const int rc = upload_scan_units(s, units);
+    if (rc != MIPT_OK) return rc;
+  }
   if (small.size() >= 2) return build_bvh(s, small);
   // zero or one triangle left: no inner node, the scene still counts as a tree scene
   HIP_TRY(hipMalloc(&s->d_bvh, sizeof(BvhNode)));
@@ -289,28 +298,32 @@ static void make_single_unit(const TriRec& t, ScanUnit& u) {
 }
 
 // per chunk of 32 triangles: pairs (greedy over consecutive indices) first, then singles
-static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>& tr, size_t n_tris,
+// `ids` lists the triangles to cover, ascending (all of them for a linear-scan scene, the big ones
+// of a tree scene); mask bit p of chunk c stands for triangle ids[32 c + p].
+static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>& tr, const std::vector<int>& ids,
                              std::vector<ScanUnit>& units, uint32_t& n_pair_units) {
-  const size_t n_chunks = (n_tris + 31) / 32;
+  const size_t n = ids.size();
+  const size_t n_chunks = (n + 31) / 32;
   units.assign(n_chunks * 32 + 1, ScanUnit{});
   n_pair_units = 0;
   const char* no_pairs = getenv("MIPT_NO_PAIRS");  // developer switch: every triangle its own unit
   const bool pairing = !(no_pairs && no_pairs[0] == '1');
   for (size_t c = 0; c < n_chunks; ++c) {
-    const size_t lo = c * 32, hi = std::min(n_tris, lo + 32);
+    const size_t lo = c * 32, hi = std::min(n, lo + 32);
     std::vector<ScanUnit> pairs, singles;
-    for (size_t i = lo; i < hi;) {
+    for (size_t p = lo; p < hi;) {
       ScanUnit u;
-      if (pairing && i + 1 < hi && std::isfinite(tr[i].kA) && std::isfinite(tr[i + 1].kA) &&
+      const int i = ids[p];
+      if (pairing && p + 1 < hi && ids[p + 1] == i + 1 && std::isfinite(tr[i].kA) && std::isfinite(tr[i + 1].kA) &&
           make_pair_unit(tris[i], tris[i + 1], u)) {
-        u.meta = (uint32_t)(i - lo) | ((uint32_t)(i + 1 - lo) << 5);
+        u.meta = (uint32_t)(p - lo) | ((uint32_t)(p + 1 - lo) << 5);
         pairs.push_back(u);
-        i += 2;
+        p += 2;
       } else {
         make_single_unit(tr[i], u);
-        u.meta = (uint32_t)(i - lo);
+        u.meta = (uint32_t)(p - lo);
         singles.push_back(u);
-        i += 1;
+        p += 1;
       }
     }
     size_t k = lo;
@@ -319,6 +332,13 @@ static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>
     units[lo].meta |= ((uint32_t)pairs.size() << 16) | ((uint32_t)(pairs.size() + singles.size()) << 24);
     n_pair_units += (uint32_t)pairs.size();
   }
+}
+
+static int upload_scan_units(MiptScene* s, const std::vector<ScanUnit>& units) {
+  HIP_TRY(hipMalloc(&s->d_units, units.size() * sizeof(ScanUnit)));
+  HIP_TRY(hipMemcpy(s->d_units, units.data(), units.size() * sizeof(ScanUnit), hipMemcpyHostToDevice));
+  s->d.units = s->d_units;
+  return MIPT_OK;
 }
 
 static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
@@ -403,13 +423,12 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
   s->d.n_spheres = (int)n_spheres;
   s->d.scale = scale;
   const char* no_bvh = getenv("MIPT_NO_BVH");  // developer switch: always scan linearly
-  if (n_tris >= MIPT_BVH_MIN_TRIS && !(no_bvh && no_bvh[0] == '1')) return build_tree_scene(s, tris, n_tris);
+  if (n_tris >= MIPT_BVH_MIN_TRIS && !(no_bvh && no_bvh[0] == '1')) return build_tree_scene(s, tris, tr, n_tris);
   std::vector<ScanUnit> units;
-  build_scan_units(tris, tr, n_tris, units, s->n_pair_units);
-  HIP_TRY(hipMalloc(&s->d_units, units.size() * sizeof(ScanUnit)));
-  HIP_TRY(hipMemcpy(s->d_units, units.data(), units.size() * sizeof(ScanUnit), hipMemcpyHostToDevice));
-  s->d.units = s->d_units;
-  return MIPT_OK;
+  std::vector<int> all(n_tris);
+  for (size_t i = 0; i < n_tris; ++i) all[i] = (int)i;
+  build_scan_units(tris, tr, all, units, s->n_pair_units);
+  return upload_scan_units(s, units);
 }
 
 extern "C" int mipt_scene_create(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,

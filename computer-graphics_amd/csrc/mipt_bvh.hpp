@@ -344,14 +344,17 @@ __device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, const DeviceSce
   T.redo = false; T.hit = false;
   // The triangles too large for the tree first (wave-uniform loop): a wall spans the scene, its
   // box would swallow every ray; tested up front it also gives the walk its first pruning bound.
-  // The record is the same for every lane: read through the constant address space (scalar loads,
-  // SGPR operands) for the filter; only candidates fetch it into registers for the full test.
-  for (int b = 0; b < sc.n_big && !(T.redo || T.hit); ++b) {
-    const int i = as_constant(sc.big_ids)[b];
-    r.n_leaves++;
-    if (!tri_candidate(as_constant(sc.tris) + i, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.Dm)) continue;
-    float t, z, x1, x2;
-    if (bvh_leaf(sc, r, i, t, z, x1, x2)) bvh_take(T, M, r, shadow, max_t, i, t, z, x1, x2);
+  // Filtered like the linear scan does it (scan units over the big list: walls come in coplanar
+  // pairs), candidates then go through the reference's test in index order.
+  for (int base = 0; base < sc.n_big; base += 32) {
+    uint32_t mask = unit_mask(sc.units + base, r.o, r.d, r.Dm);
+    r.n_leaves += (uint32_t)__popc(mask);
+    while (mask != 0 && !(T.redo || T.hit)) {
+      const int i = sc.big_ids[base + __ffs((int)mask) - 1];
+      mask &= mask - 1u;
+      float t, z, x1, x2;
+      if (bvh_leaf(sc, r, i, t, z, x1, x2)) bvh_take(T, M, r, shadow, max_t, i, t, z, x1, x2);
+    }
   }
   // a big triangle may have ended the query (any-hit found, or redo) before the tree had a say
   T.cur = (T.redo || T.hit) ? BVH_DONE : sc.bvh_root;

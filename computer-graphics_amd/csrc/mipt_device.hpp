@@ -451,6 +451,23 @@ __device__ __forceinline__ void unit_candidates(UP U, float ox, float oy, float 
   }
 }
 
+// Phase 1 over one chunk of scan units (records [0, n_units) at `chunk`, pairs first): the mask of
+// the chunk's triangles the reference could accept. Unrolled so that the scalar loads of the next
+// record overlap the arithmetic of this one (rolled, every unit waits out its own load: -9 %).
+__device__ __forceinline__ uint32_t unit_mask(const ScanUnit* chunk, V4 o, V4 d, float Dm) {
+  const ScanUnit MIPT_CONST* units = as_constant(chunk);
+  const uint32_t counts = units[0].meta >> 16;
+  const int n_pairs = (int)(counts & 0xFFu), n_units = (int)(counts >> 8);
+  uint32_t mask = 0;
+#pragma unroll 4
+  for (int k = 0; k < n_pairs; ++k)
+    unit_candidates<true>(units + k, o.x, o.y, o.z, d.x, d.y, d.z, Dm, mask);
+#pragma unroll 4
+  for (int k = n_pairs; k < n_units; ++k)
+    unit_candidates<false>(units + k, o.x, o.y, o.z, d.x, d.y, d.z, Dm, mask);
+  return mask;
+}
+
 // One triangle of the scan. FAST = false is the literal reference arithmetic. FAST = true decides
 // the gate `t >= 0 && t <= lim` (t = detM / detA, used for nothing else) from the estimate
 // detM * rcp(detA) whenever that estimate is outside a relative band of 2^-20 around 0 and lim --

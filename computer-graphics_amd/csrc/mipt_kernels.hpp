@@ -127,19 +127,7 @@ __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d
   const float Om = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
   if (!(Dm >= 9.094947e-13f && Dm <= 1.0995116e12f && Om <= 1.0995116e12f)) Dm = __builtin_inff();
   for (int base = 0; base < n; base += 32) {
-    uint32_t mask = 0;
-    // the chunk's units: pairs of coplanar triangles first, then single triangles. Unrolled so
-    // that the scalar loads of the next record overlap the arithmetic of this one (rolled, every
-    // unit waits out its own load: -9 % paths/s)
-    const ScanUnit MIPT_CONST* units = as_constant(sc.units) + base;
-    const uint32_t counts = units[0].meta >> 16;
-    const int n_pairs = (int)(counts & 0xFFu), n_units = (int)(counts >> 8);
-#pragma unroll 4
-    for (int k = 0; k < n_pairs; ++k)
-      unit_candidates<true>(units + k, o.x, o.y, o.z, d.x, d.y, d.z, Dm, mask);
-#pragma unroll 4
-    for (int k = n_pairs; k < n_units; ++k)
-      unit_candidates<false>(units + k, o.x, o.y, o.z, d.x, d.y, d.z, Dm, mask);
+    uint32_t mask = unit_mask(sc.units + base, o, d, Dm);
     prof.mark(PF_PHASE1);
     prof.count(PF_N_QUERIES, 1u);
     prof.count(PF_N_CANDS, (uint32_t)__popc(mask));
