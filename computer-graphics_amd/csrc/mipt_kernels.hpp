@@ -241,6 +241,11 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
 // Batch queries against a tree scene: persistent lanes that draw rays from a queue, so a lane whose
 // walk is over takes the next ray while its neighbours finish theirs (bvh_burst returns once half
 // the wave is done). SHADOW = existsIntersection, else closestIntersection incl. the spheres.
+#ifndef MIPT_BATCH_RESERVE
+#define MIPT_BATCH_RESERVE 128
+#endif
+constexpr unsigned long long BATCH_RESERVE = MIPT_BATCH_RESERVE;
+
 template <bool SHADOW>
 __global__ __launch_bounds__(BLOCK) void k_bvh_batch(DeviceScene sc, const float4* __restrict__ origin,
                                                      const float4* __restrict__ dir,
@@ -257,22 +262,37 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_batch(DeviceScene sc, const float
   float lim0 = 0.f;
   bool have = false, drained = false;
   uint32_t overflow = 0;
+  unsigned long long res_next = 0, res_end = 0;  // wave-uniform: the wave's reserved run of rays
   for (;;) {
     const unsigned long long need = __ballot(!have);
     if (need && !drained) {
-      unsigned long long base = 0;
-      if (lane == 0) base = atomicAdd(queue, (unsigned long long)__popcll(need));
-      base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
-             (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)base);
-      if (base >= n_rays) drained = true;
-      const unsigned long long idx = base + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
-      if (!have && idx < n_rays) {
-        my = idx;
-        const float4 of = origin[my], df = dir[my];
-        r = bvh_ray(sc, {of.x, of.y, of.z, of.w}, {df.x, df.y, df.z, df.w});
-        lim0 = SHADOW ? max_t[my] : 3.402823466e+38f;
-        bvh_begin(T, M, sc, r, SHADOW, lim0);
-        have = true;
+      // the wave reserves BATCH_RESERVE rays with one atomic and hands them to its lanes as they
+      // run dry (one atomic per handful of rays made the queue head the bottleneck of the kernel)
+      if (res_next == res_end) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(queue, (unsigned long long)BATCH_RESERVE);
+        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+               (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)base);
+        if (base >= n_rays) {
+          drained = true;
+        } else {
+          res_next = base;
+          res_end = base + BATCH_RESERVE < n_rays ? base + BATCH_RESERVE : n_rays;
+        }
+      }
+      if (!drained) {
+        const unsigned long long avail = res_end - res_next;
+        const unsigned long long rank = (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
+        if (!have && rank < avail) {
+          my = res_next + rank;
+          const float4 of = origin[my], df = dir[my];
+          r = bvh_ray(sc, {of.x, of.y, of.z, of.w}, {df.x, df.y, df.z, df.w});
+          lim0 = SHADOW ? max_t[my] : 3.402823466e+38f;
+          bvh_begin(T, M, sc, r, SHADOW, lim0);
+          have = true;
+        }
+        const unsigned long long n_need = (unsigned long long)__popcll(need);
+        res_next += n_need < avail ? n_need : avail;
       }
     }
     if (!__any(have)) break;  // every lane idle: the queue has run dry
