@@ -31,6 +31,8 @@ def make_scene(name, api, dtype):
         return np.concatenate([bigscenes.room(api), bigscenes.soup(dtype, 100000, size=0.02)])
     if name == "soup1m":
         return np.concatenate([bigscenes.room(api), bigscenes.soup(dtype, 1000000, size=0.01)])
+    if name == "wolf":  # the reference's glassWolf scene (main.cpp:78-89), from the committed fixture
+        return np.fromfile(os.path.join(ROOT, "tests", "golden", "obj", "glasswolf_scene.bin"), dtype=dtype)
     if name == "c4":
         return bigscenes.config4(api, dtype)
     if name == "c5":
