@@ -58,6 +58,103 @@ def cpu_baseline(abi, tris, cam, light, params):
             "ofast_build_paths_per_s": out["ofast_mt"]}
 
 
+def tree_workload(args):
+    """configs[3]: whole paths through the room + 102 400-triangle mesh, samples split over ranks + one
+    sum-reduce (like the Cornell workload). configs[4]: a 3840 x 2160 batch of incoherent closest-hit
+    rays against 10^6 random triangles, rays sharded over ranks, no collective. Bound: memory
+    (64-byte node / record gathers); achieved = algorithmic bytes per second."""
+    import torch
+    import torch.distributed as dist
+    import bigscenes
+    import raygen
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    pkg = graft.load_package()
+    abi, api = pkg.abi, pkg.api
+    from computer_graphics_amd import parallel
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.workload == "c4":
+        tris = bigscenes.config4(api, abi.TRIANGLE_DTYPE)
+        spp = min(args.spp, 256)
+        cam, light = api.default_camera(SIZE), api.default_light(glass=True)
+        params = api.default_params(SIZE, SIZE, rng_mode=abi.RNG_COUNTER, seed=0, fog_sigma_t=FOG_SIGMA_T,
+                                    fog_albedo=FOG_ALBEDO)
+        scene = api.Scene(tris, None, device=dev.index)
+        buf = torch.zeros(SIZE * SIZE * 3, dtype=torch.float32, device=dev)
+        total = torch.zeros_like(buf) if rank == 0 else None
+
+        def step(k):
+            begin = parallel.rank_sample_range(k * world * spp, world * spp, rank, world)[0]
+            buf.zero_()
+            scene.render_accumulate_dev(cam, light, params, begin, spp, buf)
+            parallel.reduce_image(buf, total, rank, world)
+        units_per_step, unit, label = SIZE * SIZE * spp * world, "paths/s", f"room + 102 400-triangle glass mesh (LBVH), {SIZE}x{SIZE}, {spp} spp per GPU per step, fog on; stand-in for BASELINE configs[3]"
+    else:
+        tris = bigscenes.config5(abi.TRIANGLE_DTYPE)
+        n_all = 3840 * 2160
+        lo, cnt = parallel.rank_sample_range(0, n_all, rank, world)   # rays sharded like samples: contiguous runs
+        o, d = raygen.interior_rays(n_all, seed=42)
+        to, td = torch.from_numpy(o[lo:lo + cnt]).to(dev), torch.from_numpy(d[lo:lo + cnt]).to(dev)
+        idx = torch.zeros(cnt, dtype=torch.int32, device=dev)
+        tt = torch.zeros(cnt, dtype=torch.float32, device=dev)
+        scene = api.Scene(tris, None, device=dev.index)
+
+        def step(k):
+            scene.closest_hit_dev(to, td, idx, tt)
+        units_per_step, unit, label = n_all, "rays/s", "10^6 random triangles (LBVH), 3840x2160 incoherent closest-hit rays per step, rays sharded over GPUs; BASELINE configs[4]"
+
+    for w in range(args.warmup):
+        step(w)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        value = units_per_step * args.steps / dt
+        line = {"metric": "paths/sec (+ Mrays/sec), tree scenes, MI355X" if args.workload == "c4" else "Mrays/sec, LBVH closest hit, MI355X",
+                "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "weak" if args.workload == "c4" else "strong", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic", "config": {"workload": label, "parallelism": f"x{world}"}}
+        if args.workload == "c4":
+            sp = abi.MiptParams.from_buffer_copy(bytes(params))
+            sp.flags = abi.FLAG_STATS
+            scene.render_accumulate_dev(cam, light, sp, 0, 4, buf)
+            torch.cuda.synchronize()
+            st = scene.stats()
+            rays = st.closest_rays + st.shadow_rays
+            bytes_per_path = (st.bvh_nodes * 64 + st.tri_tests * 64 + rays * 40) / st.paths
+            line["mrays_per_s"] = value * rays / st.paths / 1e6
+            line["roofline"] = {"bound": "hbm", "achieved": value / world * bytes_per_path / 1e9, "peak": 8000.0,
+                                "unit": "GB/s", "frac": value / world * bytes_per_path / 1e9 / 8000.0, "traffic": None,
+                                "note": "algorithmic bytes: 64 per tree node fetched + 64 per triangle record looked at "
+                                        "+ 40 per ray, counted by the stats variant; per GPU"}
+        print(json.dumps(line), flush=True)
+    scene.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,7 +162,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=SPP_PER_STEP, help="samples per pixel per rank per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--workload", choices=["cornell", "c4", "c5"], default="cornell",
+                    help="cornell = BASELINE configs[1]/[2] (the bench line the driver records); c4 / c5 = the "
+                         "tree-scene stand-ins for configs[3] / configs[4] (extra lines, same JSON shape)")
     args = ap.parse_args()
+    if args.workload != "cornell":
+        return tree_workload(args)
 
     import torch
     import torch.distributed as dist
