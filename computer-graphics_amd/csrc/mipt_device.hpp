@@ -172,7 +172,7 @@ __host__ __device__ inline uint32_t path_key(uint32_t seed, uint32_t pixel, uint
   return sample_key(pixel_key(seed, pixel), sample);
 }
 
-// RNG_MODE MIPT_RNG_MINSTD_PATH: a = engine state.  MIPT_RNG_COUNTER: a = key, b = draw counter.
+// RNG_MODE MIPT_RNG_MINSTD_PATH: a = engine state.  MIPT_RNG_COUNTER: a = key, b = draw number * 0x9E3779B9.
 struct Rng { uint32_t a, b; };
 
 template <int RNG_MODE>
@@ -192,8 +192,8 @@ __device__ __forceinline__ void rng_begin(Rng& r, uint32_t pkey, uint32_t sample
 template <int RNG_MODE>
 __device__ __forceinline__ float rng_next(Rng& r) {
   if (RNG_MODE == MIPT_RNG_COUNTER) {
-    r.b += 1u;
-    uint32_t h = mix32(r.a + r.b * 0x9E3779B9u);
+    r.b += 0x9E3779B9u;  // b = draw number * 0x9E3779B9 (mod 2^32), kept premultiplied
+    uint32_t h = mix32(r.a + r.b);
     return (float)(h >> 8) * (1.0f / 16777216.0f);
   } else {
     // minstd_rand0: x <- 16807 x mod (2^31 - 1); 2^31 = 1 (mod 2^31 - 1) folds the 46-bit product
