@@ -246,8 +246,17 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
 #endif
 constexpr unsigned long long BATCH_RESERVE = MIPT_BATCH_RESERVE;
 
+#ifndef MIPT_BATCH_WAVES
+#define MIPT_BATCH_WAVES 8
+#endif
+#if MIPT_BATCH_WAVES
+#define MIPT_BATCH_OCC __attribute__((amdgpu_waves_per_eu(MIPT_BATCH_WAVES, MIPT_BATCH_WAVES)))
+#else
+#define MIPT_BATCH_OCC
+#endif
+
 template <bool SHADOW>
-__global__ __launch_bounds__(BLOCK) void k_bvh_batch(DeviceScene sc, const float4* __restrict__ origin,
+__global__ __launch_bounds__(BLOCK) MIPT_BATCH_OCC void k_bvh_batch(DeviceScene sc, const float4* __restrict__ origin,
                                                      const float4* __restrict__ dir,
                                                      const float* __restrict__ max_t, unsigned long long n_rays,
                                                      unsigned long long* __restrict__ queue,
@@ -362,7 +371,13 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_batch(DeviceScene sc, const float
 #ifndef MIPT_WAVES_PER_EU
 #define MIPT_WAVES_PER_EU 5
 #endif
-#define MIPT_PATHS_OCC __attribute__((amdgpu_waves_per_eu(MIPT_WAVES_PER_EU, MIPT_WAVES_PER_EU)))
+// tree scenes are bound by the latency of dependent node fetches: more waves, fewer registers
+#ifndef MIPT_TREE_WAVES_PER_EU
+#define MIPT_TREE_WAVES_PER_EU 6
+#endif
+#define MIPT_PATHS_OCC                                                                              \
+  __attribute__((amdgpu_waves_per_eu(KIND == SCENE_BVH ? MIPT_TREE_WAVES_PER_EU : MIPT_WAVES_PER_EU, \
+                                     KIND == SCENE_BVH ? MIPT_TREE_WAVES_PER_EU : MIPT_WAVES_PER_EU)))
 
 template <int RNG_MODE, bool STATS, bool LIST, int KIND>
 __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a) {
