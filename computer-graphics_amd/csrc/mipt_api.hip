@@ -63,6 +63,7 @@ struct MiptScene {
   BvhNode* d_bvh = nullptr;
   int* d_big = nullptr;
   int n_tree_tris = 0;
+  int n_wide_nodes = 0;
   double bvh_build_ms = 0.0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -100,11 +101,11 @@ struct DevBuf {
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
 // LBVH over the triangles listed in `subset` (n >= 2 of them): bounds -> Morton keys -> radix sort
-// -> topology -> refit waves. Everything runs on the null stream of the scene's device; the tree
+// -> binary topology -> refit waves -> collapse into four-wide nodes, level by level. Everything runs on the null stream of the scene's device; the tree
 // is final on return.
 static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
   const int n = (int)subset.size();
-  DevBuf box, cen, scene, keys, ids, keys2, ids2, node_box, ready, done, tmp, sub;
+  DevBuf box, cen, scene, keys, ids, keys2, ids2, node_box, ready, done, tmp, sub, bin, wide, front;
   HIP_TRY(sub.alloc((size_t)n * 4));
   HIP_TRY(hipMemcpy(sub.p, subset.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   HIP_TRY(box.alloc((size_t)s->d.n_tris * sizeof(Aabb)));
@@ -115,7 +116,9 @@ static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
   HIP_TRY(node_box.alloc((size_t)n * sizeof(Aabb)));
   HIP_TRY(ready.alloc((size_t)n * 2));
   HIP_TRY(done.alloc(4));
-  HIP_TRY(hipMalloc(&s->d_bvh, (size_t)(n - 1) * sizeof(BvhNode)));
+  HIP_TRY(bin.alloc((size_t)(n - 1) * sizeof(BvhBin)));
+  HIP_TRY(wide.alloc((size_t)(n - 1) * sizeof(BvhNode)));  // one wide node per binary node at most
+  HIP_TRY(front.alloc((size_t)n * 2 * sizeof(int2)));
   struct Events {  // destroyed on every return path
     hipEvent_t a = nullptr, b = nullptr;
     ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
@@ -137,7 +140,7 @@ static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
   HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<unsigned long long>(), keys2.as<unsigned long long>(),
                                     ids.as<int>(), ids2.as<int>(), (size_t)n, 0, 63, nullptr));
   hipLaunchKernelGGL(k_bvh_topology, dim3(grid_for(n - 1)), dim3(BLOCK), 0, nullptr, keys2.as<unsigned long long>(),
-                     ids2.as<int>(), n, s->d_bvh);
+                     ids2.as<int>(), n, bin.as<BvhBin>());
   HIP_TRY(hipGetLastError());
   // refit: ready flags ping-pong between the two halves of `ready`; the count of finished nodes
   // is read back once per wave (a tree over sorted Morton keys is ~log2(n) + a few levels deep)
@@ -150,12 +153,37 @@ static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
     if (n_done == prev || ++waves > 4096)
       return fail(MIPT_E_HIP, "LBVH refit stalled at %d of %d nodes after %d waves", n_done, n - 1, waves);
     prev = n_done;
-    hipLaunchKernelGGL(k_bvh_refit, dim3(grid_for(n - 1)), dim3(BLOCK), 0, nullptr, s->d_bvh, n, box.as<Aabb>(),
+    hipLaunchKernelGGL(k_bvh_refit, dim3(grid_for(n - 1)), dim3(BLOCK), 0, nullptr, bin.as<BvhBin>(), n, box.as<Aabb>(),
                        node_box.as<Aabb>(), r1, r0, done.as<int>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(&n_done, done.p, 4, hipMemcpyDeviceToHost));
     std::swap(r0, r1);
   }
+  // collapse: the frontier holds (binary node, wide slot) pairs of one level; `done` is reused as
+  // {size of the next frontier, wide nodes allocated}
+  DevBuf counters;
+  HIP_TRY(counters.alloc(8));
+  int2* f0 = front.as<int2>();
+  int2* f1 = f0 + n;
+  const int2 root_entry = make_int2(0, 0);
+  HIP_TRY(hipMemcpy(f0, &root_entry, sizeof root_entry, hipMemcpyHostToDevice));
+  int n_front = 1, n_wide = 1, levels = 0;
+  while (n_front > 0) {
+    if (++levels > 128) return fail(MIPT_E_HIP, "LBVH collapse did not finish in %d levels", levels);
+    const int c[2] = {0, n_wide};
+    HIP_TRY(hipMemcpy(counters.p, c, 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_bvh_collapse, dim3(grid_for(n_front)), dim3(BLOCK), 0, nullptr, bin.as<BvhBin>(), f0, n_front,
+                       f1, counters.as<int>(), wide.as<BvhNode>(), counters.as<int>() + 1);
+    HIP_TRY(hipGetLastError());
+    int back[2];
+    HIP_TRY(hipMemcpy(back, counters.p, 8, hipMemcpyDeviceToHost));
+    n_front = back[0]; n_wide = back[1];
+    if (n_front > n - 1 || n_wide > n - 1) return fail(MIPT_E_HIP, "LBVH collapse overran: %d entries, %d nodes of %d", n_front, n_wide, n - 1);
+    std::swap(f0, f1);
+  }
+  HIP_TRY(hipMalloc(&s->d_bvh, (size_t)n_wide * sizeof(BvhNode)));
+  HIP_TRY(hipMemcpy(s->d_bvh, wide.p, (size_t)n_wide * sizeof(BvhNode), hipMemcpyDeviceToDevice));
+  s->n_wide_nodes = n_wide;
   HIP_TRY(hipEventRecord(e1, nullptr));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -465,7 +493,7 @@ extern "C" int mipt_scene_has_bvh(MiptScene* s, uint64_t* n_nodes, double* build
   if (n_nodes) *n_nodes = 0;
   if (build_ms) *build_ms = 0.0;
   if (!s || !s->d.bvh) return 0;
-  if (n_nodes) *n_nodes = (uint64_t)(s->n_tree_tris > 1 ? s->n_tree_tris - 1 : 0);
+  if (n_nodes) *n_nodes = (uint64_t)s->n_wide_nodes;
   if (build_ms) *build_ms = s->bvh_build_ms;
   return 1;
 }

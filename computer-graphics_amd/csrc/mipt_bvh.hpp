@@ -40,10 +40,22 @@
 
 namespace mipt {
 
-struct __attribute__((aligned(64))) BvhNode {
+// binary node of the radix tree: build-time only
+struct __attribute__((aligned(64))) BvhBin {
   float lmin[3], lmax[3], rmin[3], rmax[3];
   int left, right;
   int pad0, pad1;
+};
+
+// What the walk reads: the binary tree collapsed two levels at a time into nodes of up to four
+// children (half as many dependent fetches per ray; the walk is bound by their latency).
+// 128 bytes: boxes as lo[axis][child] / hi[axis][child], child references (>= 0 node, < 0 leaf
+// holding triangle -1 - ref, BVH_DONE = empty slot whose box is inverted and never hit).
+struct __attribute__((aligned(128))) BvhNode {
+  float lo[3][4];
+  float hi[3][4];
+  int ref[4];
+  int pad[4];
 };
 
 struct Aabb { float lo[3], hi[3]; };
@@ -137,7 +149,7 @@ __device__ __forceinline__ int bvh_delta(const unsigned long long* keys, int n, 
 // Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees"
 __global__ __launch_bounds__(BLOCK) void k_bvh_topology(const unsigned long long* __restrict__ keys,
                                                         const int* __restrict__ ids, int n,
-                                                        BvhNode* __restrict__ nodes) {
+                                                        BvhBin* __restrict__ nodes) {
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n - 1) return;
   const int d = (bvh_delta(keys, n, i, i + 1) - bvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_topology(const unsigned long long
 
 // one refit wave: every inner node whose children both have boxes computes its own.
 // node_box[0..n-2] inner, ready[] likewise; leaves take their box from tri_box.
-__global__ __launch_bounds__(BLOCK) void k_bvh_refit(BvhNode* __restrict__ nodes, int n, const Aabb* __restrict__ tri_box,
+__global__ __launch_bounds__(BLOCK) void k_bvh_refit(BvhBin* __restrict__ nodes, int n, const Aabb* __restrict__ tri_box,
                                                      Aabb* __restrict__ node_box, unsigned char* __restrict__ ready,
                                                      const unsigned char* __restrict__ ready_prev,
                                                      int* __restrict__ n_done) {
@@ -185,6 +197,56 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_refit(BvhNode* __restrict__ nodes
   node_box[i] = u;
   ready[i] = 1;
   atomicAdd(n_done, 1);
+}
+
+// One wave of the collapse: every frontier entry (binary node b, wide slot w) fills wide node w with
+// b's grandchildren (a child that is a leaf stays as it is), gives every inner grandchild a new
+// wide slot and puts it on the next frontier. Launched level by level until the frontier is empty.
+__global__ __launch_bounds__(BLOCK) void k_bvh_collapse(const BvhBin* __restrict__ bin,
+                                                        const int2* __restrict__ frontier_in, int n_in,
+                                                        int2* __restrict__ frontier_out, int* __restrict__ n_out,
+                                                        BvhNode* __restrict__ wide, int* __restrict__ n_wide) {
+  const int j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= n_in) return;
+  const int b = frontier_in[j].x, w = frontier_in[j].y;
+  const BvhBin B = bin[b];
+  int ref[4];
+  float lo[4][3], hi[4][3];
+  int m = 0;
+  for (int side = 0; side < 2; ++side) {
+    const int c = side ? B.right : B.left;
+    if (c >= 0) {
+      const BvhBin C = bin[c];
+      ref[m] = C.left;
+      for (int k = 0; k < 3; ++k) { lo[m][k] = C.lmin[k]; hi[m][k] = C.lmax[k]; }
+      ++m;
+      ref[m] = C.right;
+      for (int k = 0; k < 3; ++k) { lo[m][k] = C.rmin[k]; hi[m][k] = C.rmax[k]; }
+      ++m;
+    } else {
+      ref[m] = c;
+      for (int k = 0; k < 3; ++k) { lo[m][k] = side ? B.rmin[k] : B.lmin[k]; hi[m][k] = side ? B.rmax[k] : B.lmax[k]; }
+      ++m;
+    }
+  }
+  BvhNode N;
+  for (int c = 0; c < 4; ++c) {
+    if (c < m) {
+      for (int k = 0; k < 3; ++k) { N.lo[k][c] = lo[c][k]; N.hi[k][c] = hi[c][k]; }
+      if (ref[c] >= 0) {
+        const int slot = atomicAdd(n_wide, 1);
+        frontier_out[atomicAdd(n_out, 1)] = make_int2(ref[c], slot);
+        N.ref[c] = slot;
+      } else {
+        N.ref[c] = ref[c];
+      }
+    } else {
+      for (int k = 0; k < 3; ++k) { N.lo[k][c] = __builtin_inff(); N.hi[k][c] = -__builtin_inff(); }
+      N.ref[c] = (int)0x80000000;
+    }
+    N.pad[c] = 0;
+  }
+  wide[w] = N;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -223,10 +285,11 @@ __device__ __forceinline__ void tri_eval(TP T, float ox, float oy, float oz, flo
 
 struct BvhHit { int idx; float t, z, by, bz; };
 
-// A tree over sorted 63-bit keys, equal keys split by their 32-bit position, is at most 95 levels
-// deep, and the traversal pushes at most one entry per level: the stack cannot overflow.
+// A binary tree over sorted 63-bit keys, equal keys split by their 32-bit position, is at most 95
+// levels deep, i.e. 48 levels of four-wide nodes, and the walk pushes at most three entries per
+// level: a stack of 144 cannot overflow.
 #ifndef MIPT_BVH_STACK
-#define MIPT_BVH_STACK 96
+#define MIPT_BVH_STACK 144
 #endif
 constexpr int BVH_STACK = MIPT_BVH_STACK;
 // a burst of the walk ends when fewer than KEEP_NUM / KEEP_DEN of the lanes that entered it still walk
@@ -251,6 +314,49 @@ __device__ __forceinline__ bool slab(const float lo[3], const float hi[3], V3 o,
   const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
   tnear = t0;
   return t0 <= t1 * 1.0000004f + 1e-30f && t1 >= 0.f && t0 <= bound;
+}
+
+// One child of a wide node against the ray: entry distance in tnear, true if the box is hit in
+// front of the origin and not beyond `bound`.
+__device__ __forceinline__ bool slab4(const BvhNode& N, int c, V3 o, V3 inv, float bound, float& tnear) {
+  const float lo[3] = {N.lo[0][c], N.lo[1][c], N.lo[2][c]}, hi[3] = {N.hi[0][c], N.hi[1][c], N.hi[2][c]};
+  return slab(lo, hi, o, inv, bound, tnear);
+}
+
+// A step through an inner node: the nearest child hit becomes the next node, the other hit children
+// go on the stack (farthest first, so that nearer ones are walked earlier and prune more). The four
+// (entry distance, reference) pairs go through a five-exchange sorting network with misses at
+// +inf; nothing is indexed by a run-time value, so the node stays in registers.
+// Returns false if the stack is full (cannot happen: <= 3 pushes per level, <= 48 levels).
+__device__ __forceinline__ void bvh_cswap(float& ta, int& ra, float& tb, int& rb) {
+  const bool s = tb < ta;
+  const float t = s ? tb : ta, u = s ? ta : tb;
+  const int r = s ? rb : ra, q = s ? ra : rb;
+  ta = t; tb = u; ra = r; rb = q;
+}
+__device__ __forceinline__ bool bvh_step(const BvhNode& N, V3 o, V3 inv, float bound, int& cur, int* stack, int& sp) {
+  const float inf = __builtin_inff();
+  float t0, t1, t2, t3;
+  t0 = (slab4(N, 0, o, inv, bound, t0) && N.ref[0] != BVH_DONE) ? t0 : inf;  // empty slots never hit
+  t1 = (slab4(N, 1, o, inv, bound, t1) && N.ref[1] != BVH_DONE) ? t1 : inf;
+  t2 = (slab4(N, 2, o, inv, bound, t2) && N.ref[2] != BVH_DONE) ? t2 : inf;
+  t3 = (slab4(N, 3, o, inv, bound, t3) && N.ref[3] != BVH_DONE) ? t3 : inf;
+  int r0 = N.ref[0], r1 = N.ref[1], r2 = N.ref[2], r3 = N.ref[3];
+  bvh_cswap(t0, r0, t1, r1);
+  bvh_cswap(t2, r2, t3, r3);
+  bvh_cswap(t0, r0, t2, r2);
+  bvh_cswap(t1, r1, t3, r3);
+  bvh_cswap(t1, r1, t2, r2);
+  if (!(t0 < inf)) {
+    cur = sp ? stack[--sp] : BVH_DONE;
+    return true;
+  }
+  if (sp + 3 > BVH_STACK) return false;
+  if (t3 < inf) stack[sp++] = r3;
+  if (t2 < inf) stack[sp++] = r2;
+  if (t1 < inf) stack[sp++] = r1;
+  cur = r0;
+  return true;
 }
 
 struct BvhRay {
@@ -373,19 +479,7 @@ __device__ __forceinline__ void bvh_burst(BvhTrav& T, BvhMem& M, const DeviceSce
     while (T.cur >= 0) {
       const BvhNode N = nodes[T.cur];
       r.n_nodes++;
-      float tl, tr;
-      const bool hl = slab(N.lmin, N.lmax, r.oo, r.inv, T.bound, tl);
-      const bool hr = slab(N.rmin, N.rmax, r.oo, r.inv, T.bound, tr);
-      if (hl && hr) {
-        const bool left_first = tl <= tr;
-        if (T.sp >= BVH_STACK) { overflow++; T.redo = true; T.cur = BVH_DONE; break; }
-        M.stack[T.sp++] = left_first ? N.right : N.left;
-        T.cur = left_first ? N.left : N.right;
-      } else if (hl || hr) {
-        T.cur = hl ? N.left : N.right;
-      } else {
-        T.cur = T.sp ? M.stack[--T.sp] : BVH_DONE;
-      }
+      if (!bvh_step(N, r.oo, r.inv, T.bound, T.cur, M.stack, T.sp)) { overflow++; T.redo = true; T.cur = BVH_DONE; break; }
     }
     if (T.cur != BVH_DONE) {
       const int i = -1 - T.cur;
@@ -451,19 +545,7 @@ __device__ __forceinline__ void bvh_closest_exhaustive(const DeviceScene& sc, co
       }
       const BvhNode N = nodes[cur];
       r.n_nodes++;
-      float tl, tr;
-      const bool hl = slab(N.lmin, N.lmax, r.oo, r.inv, 3.402823466e+38f, tl);
-      const bool hr = slab(N.rmin, N.rmax, r.oo, r.inv, 3.402823466e+38f, tr);
-      if (hl && hr) {
-        if (sp >= BVH_STACK) { overflow++; return; }
-        stack[sp++] = N.right;
-        cur = N.left;
-      } else if (hl || hr) {
-        cur = hl ? N.left : N.right;
-      } else {
-        if (sp == 0) break;
-        cur = stack[--sp];
-      }
+      if (!bvh_step(N, r.oo, r.inv, 3.402823466e+38f, cur, stack, sp)) { overflow++; return; }
     }
     if (best == 0x7FFFFFFF) return;
     h.set_lim(bz);

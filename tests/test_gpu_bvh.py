@@ -43,7 +43,8 @@ def test_tree_equals_literal_scan_on_device(api, O, dtype, name):
     has, n_nodes, build_ms = sc.bvh_info()
     # the ten wall triangles (and at most 54 other large ones) stay out of the tree: they are
     # tested one by one before the walk
-    assert has and len(tris) - 64 - 1 <= n_nodes <= len(tris) - 10 - 1
+    # four-wide nodes: between a third (every node full) and all of the n - 1 binary nodes
+    assert has and (len(tris) - 64) // 3 <= n_nodes <= len(tris) - 10 - 1
     n_rays = (1 << 22) if len(tris) < 50000 else (1 << 20)
     rcp_bad, _, closest_bad, any_bad = sc.selfcheck(n_rays, seed=5)
     redo, overflow = sc.last_selfcheck_bvh
