@@ -62,7 +62,7 @@ def tree_workload(args):
     """configs[3]: whole paths through the room + 102 400-triangle mesh, samples split over ranks + one
     sum-reduce (like the Cornell workload). configs[4]: a 3840 x 2160 batch of incoherent closest-hit
     rays against 10^6 random triangles, rays sharded over ranks, no collective. Bound: memory
-    (128-byte node / 64-byte record gathers); achieved = algorithmic bytes per second."""
+    (64-byte node / record gathers); achieved = algorithmic bytes per second."""
     import torch
     import torch.distributed as dist
     import bigscenes
@@ -142,11 +142,11 @@ def tree_workload(args):
             torch.cuda.synchronize()
             st = scene.stats()
             rays = st.closest_rays + st.shadow_rays
-            bytes_per_path = (st.bvh_nodes * 128 + st.tri_tests * 64 + rays * 40) / st.paths
+            bytes_per_path = (st.bvh_nodes * 64 + st.tri_tests * 64 + rays * 40) / st.paths
             line["mrays_per_s"] = value * rays / st.paths / 1e6
             line["roofline"] = {"bound": "hbm", "achieved": value / world * bytes_per_path / 1e9, "peak": 8000.0,
                                 "unit": "GB/s", "frac": value / world * bytes_per_path / 1e9 / 8000.0, "traffic": None,
-                                "note": "algorithmic bytes: 128 per four-wide tree node fetched + 64 per triangle record looked at "
+                                "note": "algorithmic bytes: 64 per four-wide tree node fetched + 64 per triangle record looked at "
                                         "+ 40 per ray, counted by the stats variant; per GPU"}
         print(json.dumps(line), flush=True)
     scene.close()

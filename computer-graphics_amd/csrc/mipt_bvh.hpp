@@ -10,8 +10,9 @@
 //   build     triangle bounds -> 63-bit Morton keys of the centroids -> radix sort (rocPRIM) ->
 //             Karras' parallel radix-tree construction -> bottom-up refit, one launch per level
 //             wave (kernel boundaries order the writes; no inter-workgroup flags).
-//   node      64 bytes: the two children's boxes and two child references (>= 0 inner node,
-//             < 0 leaf holding triangle -1 - ref). One node = one 64-byte line.
+//   node      the binary tree is collapsed into nodes of up to four children, 64 bytes each with
+//             the children's boxes on a per-node 8-bit grid (BvhNode below); references are
+//             >= 0 inner node, < 0 leaf holding triangle -1 - ref.
 //   leaf box  the triangle's bounds grown by 3 % of its extent: the candidate filter
 //             (tri_candidate) admits hits up to 2 % of an edge outside the triangle.
 //   closest   stack traversal, near child first; at a leaf the candidate filter, then the
@@ -48,15 +49,34 @@ struct __attribute__((aligned(64))) BvhBin {
 };
 
 // What the walk reads: the binary tree collapsed two levels at a time into nodes of up to four
-// children (half as many dependent fetches per ray; the walk is bound by their latency).
-// 128 bytes: boxes as lo[axis][child] / hi[axis][child], child references (>= 0 node, < 0 leaf
-// holding triangle -1 - ref, BVH_DONE = empty slot whose box is inverted and never hit).
+// children (half as many dependent fetches per ray). Child references: >= 0 node, < 0 leaf holding
+// triangle -1 - ref, BVH_DONE = empty slot, never hit.
+#ifndef MIPT_BVH_QUANT
+#define MIPT_BVH_QUANT 1
+#endif
+#if MIPT_BVH_QUANT
+// 64 bytes: the children's boxes on a per-node grid of 256 steps per axis. A bound is
+// org[axis] + q * 2^(e[axis] - 127), decoded with one fused multiply-add; the build rounds lower
+// bounds down and upper bounds up against that very expression, so a decoded box always contains
+// the exact one (the walk visits a few more nodes, never fewer). One node = four 16-byte loads
+// per lane: the walk's rays diverge, so its cost is the number of lines the L1 has to look up.
+struct __attribute__((aligned(64))) BvhNode {
+  float org[3];
+  uint32_t ex;      // byte k: biased exponent of axis k's grid step
+  uint32_t qlo[3];  // word k, byte c: lower bound of child c on axis k, in grid steps
+  uint32_t qhi[3];
+  int ref[4];
+  int pad[2];
+};
+#else
+// 128 bytes: boxes as lo[axis][child] / hi[axis][child] in full precision
 struct __attribute__((aligned(128))) BvhNode {
   float lo[3][4];
   float hi[3][4];
   int ref[4];
   int pad[4];
 };
+#endif
 
 struct Aabb { float lo[3], hi[3]; };
 
@@ -231,21 +251,59 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_collapse(const BvhBin* __restrict
   }
   BvhNode N;
   for (int c = 0; c < 4; ++c) {
-    if (c < m) {
-      for (int k = 0; k < 3; ++k) { N.lo[k][c] = lo[c][k]; N.hi[k][c] = hi[c][k]; }
-      if (ref[c] >= 0) {
-        const int slot = atomicAdd(n_wide, 1);
-        frontier_out[atomicAdd(n_out, 1)] = make_int2(ref[c], slot);
-        N.ref[c] = slot;
-      } else {
-        N.ref[c] = ref[c];
-      }
+    if (c < m && ref[c] >= 0) {
+      const int slot = atomicAdd(n_wide, 1);
+      frontier_out[atomicAdd(n_out, 1)] = make_int2(ref[c], slot);
+      N.ref[c] = slot;
     } else {
-      for (int k = 0; k < 3; ++k) { N.lo[k][c] = __builtin_inff(); N.hi[k][c] = -__builtin_inff(); }
-      N.ref[c] = (int)0x80000000;
+      N.ref[c] = c < m ? ref[c] : (int)0x80000000;
+    }
+  }
+#if MIPT_BVH_QUANT
+  N.ex = 0;
+  N.pad[0] = N.pad[1] = 0;
+  const float inf = __builtin_inff();
+  for (int k = 0; k < 3; ++k) {
+    float org = inf, top = -inf;
+    for (int c = 0; c < m; ++c) { org = fminf(org, lo[c][k]); top = fmaxf(top, hi[c][k]); }
+    if (!(fabsf(org) < inf)) org = 0.f;  // boxes of NaN triangles only: nothing to find in them
+    // smallest power of two with 255 steps covering the extent, raised until every bound fits
+    uint32_t e = ((__float_as_uint((top - org) / 255.f) >> 23) & 0xFFu) + 1u;
+    e = e < 1u ? 1u : (e > 254u ? 254u : e);
+    uint32_t wlo = 0, whi = 0;
+    for (;;) {
+      const float step = __uint_as_float(e << 23), inv_step = 1.f / step;
+      bool ok = true;
+      wlo = 0; whi = 0;
+      for (int c = 0; c < 4; ++c) {
+        float ql = 255.f, qh = 0.f;  // empty slot: inverted
+        if (c < m) {
+          ql = fminf(fmaxf(floorf((lo[c][k] - org) * inv_step), 0.f), 255.f);
+          while (ql > 0.f && __fmaf_rn(ql, step, org) > lo[c][k]) ql -= 1.f;
+          qh = fminf(fmaxf(ceilf((hi[c][k] - org) * inv_step), 0.f), 255.f);
+          while (qh < 255.f && __fmaf_rn(qh, step, org) < hi[c][k]) qh += 1.f;
+          if (__fmaf_rn(qh, step, org) < hi[c][k]) ok = false;
+        }
+        wlo |= (uint32_t)ql << (8 * c);
+        whi |= (uint32_t)qh << (8 * c);
+      }
+      if (ok || e >= 254u) break;
+      ++e;
+    }
+    N.org[k] = org;
+    N.ex |= e << (8 * k);
+    N.qlo[k] = wlo;
+    N.qhi[k] = whi;
+  }
+#else
+  for (int c = 0; c < 4; ++c) {
+    for (int k = 0; k < 3; ++k) {
+      N.lo[k][c] = c < m ? lo[c][k] : __builtin_inff();
+      N.hi[k][c] = c < m ? hi[c][k] : -__builtin_inff();
     }
     N.pad[c] = 0;
   }
+#endif
   wide[w] = N;
 }
 
@@ -318,10 +376,43 @@ __device__ __forceinline__ bool slab(const float lo[3], const float hi[3], V3 o,
 
 // One child of a wide node against the ray: entry distance in tnear, true if the box is hit in
 // front of the origin and not beyond `bound`.
-__device__ __forceinline__ bool slab4(const BvhNode& N, int c, V3 o, V3 inv, float bound, float& tnear) {
-  const float lo[3] = {N.lo[0][c], N.lo[1][c], N.lo[2][c]}, hi[3] = {N.hi[0][c], N.hi[1][c], N.hi[2][c]};
-  return slab(lo, hi, o, inv, bound, tnear);
+#if MIPT_BVH_QUANT
+// The ray in a node's grid: the distance to the plane `q` steps up axis k is q * ks[k] + kb[k].
+// Rounding moves a plane by <= 2^-22 of (node extent + distance to the origin), far inside the
+// padding of the leaf boxes. An infinite inverse direction gives NaN or a same-signed infinity on
+// both planes of the axis: fminf / fmaxf drop the NaNs (no constraint from that axis, conservative)
+// and the infinities reject exactly the rays outside the slab.
+struct NodeRay { float ks[3], kb[3]; };
+__device__ __forceinline__ NodeRay node_ray(const BvhNode& N, V3 o, V3 inv) {
+  NodeRay R;
+  const float oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    R.ks[k] = __uint_as_float(((N.ex >> (8 * k)) & 0xFFu) << 23) * ii[k];
+    R.kb[k] = (N.org[k] - oo[k]) * ii[k];
+  }
+  return R;
 }
+__device__ __forceinline__ bool slab4(const BvhNode& N, const NodeRay& R, int c, float bound, float& tnear) {
+  float a[3], b[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    a[k] = __fmaf_rn((float)((N.qlo[k] >> (8 * c)) & 0xFFu), R.ks[k], R.kb[k]);
+    b[k] = __fmaf_rn((float)((N.qhi[k] >> (8 * c)) & 0xFFu), R.ks[k], R.kb[k]);
+  }
+  const float t0 = fmaxf(fmaxf(fminf(a[0], b[0]), fminf(a[1], b[1])), fminf(a[2], b[2]));
+  const float t1 = fminf(fminf(fmaxf(a[0], b[0]), fmaxf(a[1], b[1])), fmaxf(a[2], b[2]));
+  tnear = t0;
+  return t0 <= t1 * 1.0000004f + 1e-30f && t1 >= 0.f && t0 <= bound;
+}
+#else
+struct NodeRay { V3 o, inv; };
+__device__ __forceinline__ NodeRay node_ray(const BvhNode&, V3 o, V3 inv) { return NodeRay{o, inv}; }
+__device__ __forceinline__ bool slab4(const BvhNode& N, const NodeRay& R, int c, float bound, float& tnear) {
+  const float lo[3] = {N.lo[0][c], N.lo[1][c], N.lo[2][c]}, hi[3] = {N.hi[0][c], N.hi[1][c], N.hi[2][c]};
+  return slab(lo, hi, R.o, R.inv, bound, tnear);
+}
+#endif
 
 // A step through an inner node: the nearest child hit becomes the next node, the other hit children
 // go on the stack (farthest first, so that nearer ones are walked earlier and prune more). The four
@@ -337,10 +428,11 @@ __device__ __forceinline__ void bvh_cswap(float& ta, int& ra, float& tb, int& rb
 __device__ __forceinline__ bool bvh_step(const BvhNode& N, V3 o, V3 inv, float bound, int& cur, int* stack, int& sp) {
   const float inf = __builtin_inff();
   float t0, t1, t2, t3;
-  t0 = (slab4(N, 0, o, inv, bound, t0) && N.ref[0] != BVH_DONE) ? t0 : inf;  // empty slots never hit
-  t1 = (slab4(N, 1, o, inv, bound, t1) && N.ref[1] != BVH_DONE) ? t1 : inf;
-  t2 = (slab4(N, 2, o, inv, bound, t2) && N.ref[2] != BVH_DONE) ? t2 : inf;
-  t3 = (slab4(N, 3, o, inv, bound, t3) && N.ref[3] != BVH_DONE) ? t3 : inf;
+  const NodeRay R = node_ray(N, o, inv);
+  t0 = (slab4(N, R, 0, bound, t0) && N.ref[0] != BVH_DONE) ? t0 : inf;  // empty slots never hit
+  t1 = (slab4(N, R, 1, bound, t1) && N.ref[1] != BVH_DONE) ? t1 : inf;
+  t2 = (slab4(N, R, 2, bound, t2) && N.ref[2] != BVH_DONE) ? t2 : inf;
+  t3 = (slab4(N, R, 3, bound, t3) && N.ref[3] != BVH_DONE) ? t3 : inf;
   int r0 = N.ref[0], r1 = N.ref[1], r2 = N.ref[2], r3 = N.ref[3];
   bvh_cswap(t0, r0, t1, r1);
   bvh_cswap(t2, r2, t3, r3);

@@ -108,8 +108,8 @@ def main():
         n_rays_st = max(st.closest_rays + st.shadow_rays, 1)
         row["nodes_per_ray"] = round(st.bvh_nodes / n_rays_st, 1)
         row["leaves_per_ray"] = round(st.tri_tests / n_rays_st, 1)
-        # algorithmic bytes of the traversal: 128 B per four-wide node fetched, 64 B per triangle record looked at
-        bytes_per_ray = (st.bvh_nodes * 128 + st.tri_tests * 64) / n_rays_st
+        # algorithmic bytes of the traversal: 64 B per four-wide node fetched, 64 B per triangle record looked at
+        bytes_per_ray = (st.bvh_nodes * 64 + st.tri_tests * 64) / n_rays_st
         row["paths_algorithmic_GB_s"] = round(row["paths_Mrays_s"] * 1e6 * bytes_per_ray / 1e9, 1)
         sc.close()
         print(json.dumps(row), flush=True)
