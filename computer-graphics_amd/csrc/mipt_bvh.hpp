@@ -250,11 +250,15 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_collapse(const BvhBin* __restrict
     }
   }
   BvhNode N;
+  // the inner children get consecutive slots: siblings a ray visits together share lines
+  int n_inner = 0;
+  for (int c = 0; c < m; ++c) n_inner += ref[c] >= 0;
+  int slot = n_inner ? atomicAdd(n_wide, n_inner) : 0;
+  int entry = n_inner ? atomicAdd(n_out, n_inner) : 0;
   for (int c = 0; c < 4; ++c) {
     if (c < m && ref[c] >= 0) {
-      const int slot = atomicAdd(n_wide, 1);
-      frontier_out[atomicAdd(n_out, 1)] = make_int2(ref[c], slot);
-      N.ref[c] = slot;
+      frontier_out[entry++] = make_int2(ref[c], slot);
+      N.ref[c] = slot++;
     } else {
       N.ref[c] = c < m ? ref[c] : (int)0x80000000;
     }

@@ -4,9 +4,15 @@ under profiles/: per-kernel call count / total / average duration (the `--stats`
 for --pmc runs, per-kernel sums of every collected counter.
 
     python tools/rocpd_summary.py <results.db> [more.db ...] > profiles/<name>.txt
+
+Kernel names are cut to 160 characters (rocPRIM's template names run to kilobytes).
 """
 import sqlite3
 import sys
+
+
+def short(name, width=160):
+    return name if len(name) <= width else name[:width - 3] + "..."
 
 
 def main():
@@ -19,7 +25,7 @@ def main():
             print("## kernel-trace --stats (durations in microseconds)")
             print(f"{'calls':>6} {'total_us':>14} {'avg_us':>14} {'pct':>7}  name")
             for name, calls, total, avg, pct in rows:
-                print(f"{calls:6d} {total:14.3f} {avg:14.3f} {pct:7.3f}  {name}")
+                print(f"{calls:6d} {total:14.3f} {avg:14.3f} {pct:7.3f}  {short(name)}")
         try:
             pmc = list(c.execute(
                 "select kernel_name, counter_name, count(distinct dispatch_id), sum(value), "
@@ -32,7 +38,7 @@ def main():
             last = None
             for k, cn, nd, v, vg, sg, lds, grid, wg in pmc:
                 if k != last:
-                    print(f"kernel {k}\n  dispatches={nd} vgpr={vg} sgpr={sg} lds={lds} grid={grid} wg={wg}")
+                    print(f"kernel {short(k)}\n  dispatches={nd} vgpr={vg} sgpr={sg} lds={lds} grid={grid} wg={wg}")
                     last = k
                 print(f"    {cn:28s} {v:.6g}")
         print()
