@@ -3,7 +3,9 @@
 under profiles/: per-kernel call count / total / average duration (the `--stats` view) and,
 for --pmc runs, per-kernel sums of every collected counter.
 
-    python tools/rocpd_summary.py <results.db> [more.db ...] > profiles/<name>.txt
+    python tools/rocpd_summary.py [--only SUBSTRING] <results.db> [more.db ...] > profiles/<name>.txt
+
+--only keeps the kernels whose name contains SUBSTRING (e.g. "mipt::").
 
 Kernel names are cut to 160 characters (rocPRIM's template names run to kilobytes).
 """
@@ -16,7 +18,11 @@ def short(name, width=160):
 
 
 def main():
-    for path in sys.argv[1:]:
+    args = sys.argv[1:]
+    only = None
+    if args and args[0] == "--only":
+        only, args = args[1], args[2:]
+    for path in args:
         db = sqlite3.connect(path)
         c = db.cursor()
         print(f"# {path}")
@@ -25,6 +31,8 @@ def main():
             print("## kernel-trace --stats (durations in microseconds)")
             print(f"{'calls':>6} {'total_us':>14} {'avg_us':>14} {'pct':>7}  name")
             for name, calls, total, avg, pct in rows:
+                if only and only not in name:
+                    continue
                 print(f"{calls:6d} {total:14.3f} {avg:14.3f} {pct:7.3f}  {short(name)}")
         try:
             pmc = list(c.execute(
@@ -37,6 +45,8 @@ def main():
             print("## pmc (sum over dispatches)")
             last = None
             for k, cn, nd, v, vg, sg, lds, grid, wg in pmc:
+                if only and only not in k:
+                    continue
                 if k != last:
                     print(f"kernel {short(k)}\n  dispatches={nd} vgpr={vg} sgpr={sg} lds={lds} grid={grid} wg={wg}")
                     last = k
