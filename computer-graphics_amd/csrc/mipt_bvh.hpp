@@ -350,16 +350,23 @@ struct BvhHit { int idx; float t, z, by, bz; };
 // A binary tree over sorted 63-bit keys, equal keys split by their 32-bit position, is at most 95
 // levels deep, i.e. 48 levels of four-wide nodes, and the walk pushes at most three entries per
 // level: a stack of 144 cannot overflow.
+// weights of the burst's vote between a node step and a leaf test
+#ifndef MIPT_BVH_VOTE_NODE
+#define MIPT_BVH_VOTE_NODE 2
+#endif
+#ifndef MIPT_BVH_VOTE_LEAF
+#define MIPT_BVH_VOTE_LEAF 3
+#endif
 #ifndef MIPT_BVH_STACK
 #define MIPT_BVH_STACK 144
 #endif
 constexpr int BVH_STACK = MIPT_BVH_STACK;
 // a burst of the walk ends when fewer than KEEP_NUM / KEEP_DEN of the lanes that entered it still walk
 #ifndef MIPT_BVH_KEEP_NUM
-#define MIPT_BVH_KEEP_NUM 1
+#define MIPT_BVH_KEEP_NUM 3
 #endif
 #ifndef MIPT_BVH_KEEP_DEN
-#define MIPT_BVH_KEEP_DEN 2
+#define MIPT_BVH_KEEP_DEN 8
 #endif
 constexpr int BVH_KEEP_NUM = MIPT_BVH_KEEP_NUM, BVH_KEEP_DEN = MIPT_BVH_KEEP_DEN;
 constexpr int BVH_DONE = (int)0x80000000;  // traversal finished (leaf references are -1 - index > this)
@@ -497,6 +504,7 @@ __device__ __forceinline__ bool bvh_leaf(const DeviceScene& sc, const BvhRay& r,
 // lengths are heavy tailed: a wave that waits for its slowest ray runs at ~10 % lane occupancy).
 struct BvhTrav {
   int cur;        // node (>= 0), leaf (< 0) or BVH_DONE
+  int pend;       // a leaf met while other lanes still stepped through nodes, or BVH_DONE; cur != BVH_DONE while set
   int sp, n_list;
   float zmin, bound;
   bool redo;      // closest: the pruned walk cannot vouch for this ray, run bvh_closest_exhaustive
@@ -513,10 +521,10 @@ struct BvhMem {
 __device__ __forceinline__ void bvh_take(BvhTrav& T, BvhMem& M, const BvhRay& r, bool shadow, float max_t, int i,
                                          float t, float z, float x1, float x2) {
   if (shadow) {
-    if (t <= max_t && (x1 + x2) <= 1.0f) { T.hit = true; T.cur = BVH_DONE; }  // intersections.cpp:75-77
+    if (t <= max_t && (x1 + x2) <= 1.0f) { T.hit = true; T.cur = T.pend = BVH_DONE; }  // intersections.cpp:75-77
     return;
   }
-  if (!(fabsf(t - z) <= 0.000244140625f * z + r.delta)) { T.redo = true; T.cur = BVH_DONE; }  // 2^-12
+  if (!(fabsf(t - z) <= 0.000244140625f * z + r.delta)) { T.redo = true; T.cur = T.pend = BVH_DONE; }  // 2^-12
   if (z < T.zmin) {
     T.zmin = z;
     T.bound = T.zmin * BVH_BAND + 4.0f * r.delta;
@@ -527,7 +535,7 @@ __device__ __forceinline__ void bvh_take(BvhTrav& T, BvhMem& M, const BvhRay& r,
   }
   if (t <= T.bound) {
     if (T.n_list == BVH_LIST) {
-      T.redo = true; T.cur = BVH_DONE;
+      T.redo = true; T.cur = T.pend = BVH_DONE;
     } else {
       int k = T.n_list++;
       while (k > 0 && M.list[k - 1].idx > i) { M.list[k] = M.list[k - 1]; --k; }  // keep index order
@@ -539,6 +547,7 @@ __device__ __forceinline__ void bvh_take(BvhTrav& T, BvhMem& M, const BvhRay& r,
 __device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, const DeviceScene& sc, BvhRay& r, bool shadow,
                                           float max_t) {
   T.cur = sc.bvh_root;
+  T.pend = BVH_DONE;
   T.sp = 0; T.n_list = 0;
   T.zmin = 3.402823466e+38f;
   // any-hit: t of an accepted triangle is <= max_t; its true distance can exceed that by the filter's slack
@@ -562,30 +571,43 @@ __device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, const DeviceSce
   T.cur = (T.redo || T.hit) ? BVH_DONE : sc.bvh_root;
 }
 
-// "while-while": all walking lanes step through inner nodes until each holds a leaf (or is done),
-// then all test their leaves -- the two kinds of work are not interleaved lane by lane.
-// Closest hit (shadow = false): distance pruning + near-tie list, see the head of this file.
-// Any hit: existsIntersection is an OR over the triangles, the walk stops at the first acceptance.
-// Returns when the lane's walk is done or when fewer than `keep_num / keep_den` of the lanes that
-// entered are still walking.
+// Each round the wave does ONE kind of work, a node step or a leaf test, whichever more of its
+// lanes are ready for. A lane that arrives at a leaf while the wave goes on stepping through nodes
+// sets the leaf aside (T.pend) and carries on with the next entry of its stack, so it is ready for
+// both kinds; the order in which leaves are tested does not matter to the result (head of this file).
+// Closest hit (shadow = false): distance pruning + near-tie list. Any hit: existsIntersection is an
+// OR over the triangles, the walk stops at the first acceptance.
+// Returns when the lane's walk is done or when fewer than BVH_KEEP_NUM / BVH_KEEP_DEN of the lanes
+// that entered are still walking.
 __device__ __forceinline__ void bvh_burst(BvhTrav& T, BvhMem& M, const DeviceScene& sc, const BvhNode* __restrict__ nodes,
                                           BvhRay& r, bool shadow, float max_t, uint32_t& overflow) {
   const int entered = __popcll(__ballot(T.cur != BVH_DONE));
   while (T.cur != BVH_DONE) {
-    while (T.cur >= 0) {
-      const BvhNode N = nodes[T.cur];
-      r.n_nodes++;
-      if (!bvh_step(N, r.oo, r.inv, T.bound, T.cur, M.stack, T.sp)) { overflow++; T.redo = true; T.cur = BVH_DONE; break; }
-    }
-    if (T.cur != BVH_DONE) {
-      const int i = -1 - T.cur;
-      float t, z, x1, x2;
-      r.n_leaves++;
-      T.cur = T.sp ? M.stack[--T.sp] : BVH_DONE;
-      if (bvh_leaf(sc, r, i, t, z, x1, x2)) {
-        bvh_take(T, M, r, shadow, max_t, i, t, z, x1, x2);
+    if (T.cur < 0 && T.pend == BVH_DONE && T.sp > 0) { T.pend = T.cur; T.cur = M.stack[--T.sp]; }
+    const int n_node = __popcll(__ballot(T.cur >= 0));
+    const int n_leaf = __popcll(__ballot(T.pend != BVH_DONE || T.cur < 0));
+    if (MIPT_BVH_VOTE_NODE * n_node >= MIPT_BVH_VOTE_LEAF * n_leaf) {
+      if (T.cur >= 0) {
+        const BvhNode N = nodes[T.cur];
+        r.n_nodes++;
+        if (!bvh_step(N, r.oo, r.inv, T.bound, T.cur, M.stack, T.sp)) { overflow++; T.redo = true; T.cur = T.pend = BVH_DONE; }
+      }
+    } else {
+      int leaf = T.pend;
+      if (leaf != BVH_DONE) {
+        T.pend = BVH_DONE;
+      } else if (T.cur < 0) {
+        leaf = T.cur;
+        T.cur = T.sp ? M.stack[--T.sp] : BVH_DONE;
+      }
+      if (leaf != BVH_DONE) {
+        const int i = -1 - leaf;
+        float t, z, x1, x2;
+        r.n_leaves++;
+        if (bvh_leaf(sc, r, i, t, z, x1, x2)) bvh_take(T, M, r, shadow, max_t, i, t, z, x1, x2);
       }
     }
+    if (T.cur == BVH_DONE && T.pend != BVH_DONE) { T.cur = T.pend; T.pend = BVH_DONE; }
     // lanes still walking (this ballot is taken by the lanes inside the loop only)
     if (BVH_KEEP_DEN * (int)__popcll(__ballot(T.cur != BVH_DONE)) < BVH_KEEP_NUM * entered) break;
   }
