@@ -246,10 +246,9 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
 #endif
 constexpr unsigned long long BATCH_RESERVE = MIPT_BATCH_RESERVE;
 
-// latency bound: 8 waves per SIMD (64 registers; a quantised four-wide node is 14 words in flight)
-// beat 7 and 6 on the large scenes and tie on the small ones
+// measured best of 5..8 waves per SIMD with the vote-scheduled walk (8: spills, 6: ties on the largest scenes)
 #ifndef MIPT_BATCH_WAVES
-#define MIPT_BATCH_WAVES 8
+#define MIPT_BATCH_WAVES 7
 #endif
 #if MIPT_BATCH_WAVES
 #define MIPT_BATCH_OCC __attribute__((amdgpu_waves_per_eu(MIPT_BATCH_WAVES, MIPT_BATCH_WAVES)))
@@ -375,7 +374,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_BATCH_OCC void k_bvh_batch(DeviceScene 
 #endif
 // tree scenes are bound by the latency of dependent node fetches; measured best of 4, 5, 6
 #ifndef MIPT_TREE_WAVES_PER_EU
-#define MIPT_TREE_WAVES_PER_EU 6
+#define MIPT_TREE_WAVES_PER_EU 5
 #endif
 #define MIPT_PATHS_OCC                                                                              \
   __attribute__((amdgpu_waves_per_eu(KIND == SCENE_BVH ? MIPT_TREE_WAVES_PER_EU : MIPT_WAVES_PER_EU, \
