@@ -393,3 +393,44 @@ def test_maximum_depth_long_paths(api, O, pkg, with_sphere):
     p.max_depth = 17
     with pytest.raises(api.MiptError):
         api.Scene(tris).render_accumulate(cam, light, p, 0, 1)
+
+
+def test_full_size_launch_properties(api, O, pkg):
+    # BASELINE's quoted configuration in full: GlassCube, 1024 x 1024, 1024 samples per pixel in one
+    # launch (2^30 paths). No CPU can check that many paths, so: the shipped kernel against the
+    # counting kernel (every triangle in index order, every shadow ray, like the reference) bit for
+    # bit; the counters against what the reference's loop structure implies; two half launches
+    # against the whole one.
+    import torch
+    abi = pkg.abi
+    tris = O.load_test_model(2)
+    S, spp = 1024, 1024
+    cam, light = O.default_camera(S), O.default_light(True)
+    sc = api.Scene(tris)
+    dev = torch.device("cuda", 0)
+
+    def launch(begin, count, flags=0, into=None):
+        acc = torch.zeros(S * S * 3, dtype=torch.float32, device=dev) if into is None else into
+        p = O.default_params(S, S, seed=0, rng_mode=abi.RNG_COUNTER, fog_sigma_t=0.1, flags=flags)
+        sc.render_accumulate_dev(cam, light, p, begin, count, acc)
+        torch.cuda.synchronize()
+        return acc
+
+    whole = launch(0, spp)
+    counted = launch(0, spp, flags=abi.FLAG_STATS)
+    st = sc.stats()
+    assert torch.equal(whole.view(torch.int32), counted.view(torch.int32))
+    assert st.paths == S * S * spp
+    # every path casts at least its camera ray and at most MAX_DEPTH + 1 segments and one shadow ray
+    assert st.paths <= st.closest_rays <= 11 * st.paths
+    assert st.shadow_rays <= st.paths
+    assert 3.0 < (st.closest_rays + st.shadow_rays) / st.paths < 6.0
+    # closestIntersection looks at every triangle, existsIntersection stops at the first blocker
+    assert st.closest_rays * len(tris) <= st.tri_tests <= (st.closest_rays + st.shadow_rays) * len(tris)
+    halves = launch(0, spp // 2)
+    halves = launch(spp // 2, spp // 2, into=halves)
+    sc.close()
+    w, h = whole.cpu().numpy(), halves.cpu().numpy()
+    # (sums can be negative: the reference weights a bounce by an unclamped 4-component dot product)
+    assert np.isfinite(w).all() and w.sum() > 0
+    assert np.allclose(w, h, rtol=1e-5, atol=1e-4)
