@@ -33,19 +33,23 @@ def scenes(O, dtype):
         "mesh9k": bigscenes.mesh_in_room(O, dtype, cells=48, nu=64, nv=32),            # 8 714
         "mesh140k": bigscenes.mesh_in_room(O, dtype, cells=192, nu=256, nv=128),       # 139 274
         "soup20k": np.concatenate([bigscenes.room(O), bigscenes.soup(dtype, 20000)]),
+        "config4": lambda: bigscenes.config4(O, dtype),                                # 102 410
+        "config5": lambda: bigscenes.config5(dtype),                                   # 1 000 000
     }
 
 
-@pytest.mark.parametrize("name", ["mesh9k", "mesh140k", "soup20k"])
+@pytest.mark.parametrize("name", ["mesh9k", "mesh140k", "soup20k", "config4", "config5"])
 def test_tree_equals_literal_scan_on_device(api, O, dtype, name):
     tris = scenes(O, dtype)[name]
+    if callable(tris):  # the two largest are only built when asked for
+        tris = tris()
     sc = api.Scene(tris)
     has, n_nodes, build_ms = sc.bvh_info()
     # the ten wall triangles (and at most 54 other large ones) stay out of the tree: they are
     # tested one by one before the walk
     # four-wide nodes: between a third (every node full) and all of the n - 1 binary nodes
     assert has and (len(tris) - 64) // 3 <= n_nodes <= len(tris) - 10 - 1
-    n_rays = (1 << 22) if len(tris) < 50000 else (1 << 20)
+    n_rays = (1 << 22) if len(tris) < 50000 else (1 << 20) if len(tris) < 500000 else (1 << 18)
     rcp_bad, _, closest_bad, any_bad = sc.selfcheck(n_rays, seed=5)
     redo, overflow = sc.last_selfcheck_bvh
     sc.close()
