@@ -137,7 +137,7 @@ typedef struct MiptStats {
   uint64_t glass_bounces;   /* bounceGlass calls */
   uint64_t bvh_redo;        /* LBVH scenes: rays re-run through the exhaustive traversal */
   uint64_t bvh_overflow;    /* LBVH scenes: rays whose stack / hit list overflowed (must be 0) */
-  uint64_t bvh_nodes;       /* LBVH scenes: inner nodes fetched (tri_tests then counts leaves visited) */
+  uint64_t bvh_nodes;       /* LBVH scenes: four-wide nodes fetched (tri_tests then counts leaves visited) */
   double kernel_ms;        /* device time of the last render call's path kernel */
 } MiptStats;
 
@@ -186,7 +186,7 @@ int mipt_scene_create(const MiptTriangle* tris, size_t n_tris,
                       int device, MiptScene** out);
 /* Scenes of MIPT_BVH_MIN_TRIS triangles or more get an LBVH built on the GPU at creation
  * (the reference has none: main.cpp:19 lists "KD trees?" as a TODO and always scans linearly);
- * results are those of the linear scan. Returns 1 / 0, the node count in *n_nodes (nullable)
+ * results are those of the linear scan. Returns 1 / 0, the count of four-wide 64-byte nodes in *n_nodes (nullable)
  * and the build time in *build_ms (nullable). */
 #define MIPT_BVH_MIN_TRIS 256
 int mipt_scene_has_bvh(MiptScene* scene, uint64_t* n_nodes, double* build_ms);
