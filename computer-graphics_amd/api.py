@@ -206,6 +206,10 @@ class Scene:
         """pairs of coplanar triangles the linear scan's candidate filter merged"""
         return int(self._lib.mipt_scene_pair_units(self._h))
 
+    def axis_pair_units(self):
+        """Pairs among pair_units() whose plane is normal to a coordinate axis."""
+        return int(self._lib.mipt_scene_axis_pair_units(self._h))
+
     def stats(self):
         s = abi.MiptStats()
         _check(self._lib.mipt_get_stats(self._h, C.byref(s)))

@@ -54,6 +54,7 @@ struct MiptScene {
   TriRec* d_tris = nullptr;
   ScanUnit* d_units = nullptr;
   uint32_t n_pair_units = 0;
+  uint32_t n_axis_units = 0;
   ShadeRec* d_shade = nullptr;
   SphereRec* d_spheres = nullptr;
   unsigned long long* d_stats = nullptr;
@@ -199,7 +200,7 @@ static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
 // up to MAX_BIG such triangles are tested one by one before the walk instead.
 constexpr size_t MAX_BIG = 64;
 static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>& tr, const std::vector<int>& ids,
-                             std::vector<ScanUnit>& units, uint32_t& n_pair_units);
+                             std::vector<ScanUnit>& units, uint32_t& n_pair_units, uint32_t& n_axis_units);
 static int upload_scan_units(MiptScene* s, const std::vector<ScanUnit>& units);
 static int build_tree_scene(MiptScene* s, const MiptTriangle* tris, const std::vector<TriRec>& tr, size_t n_tris) {
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -240,7 +241,7 @@ static int build_tree_scene(MiptScene* s, const MiptTriangle* tris, const std::v
   s->d.n_big = (int)big.size();
   if (!big.empty()) {  // the candidate filter's units over the big list (walls come in coplanar pairs)
     std::vector<ScanUnit> units;
-    build_scan_units(tris, tr, big, units, s->n_pair_units);
+    build_scan_units(tris, tr, big, units, s->n_pair_units, s->n_axis_units);
     const int rc = upload_scan_units(s, units);
     if (rc != MIPT_OK) return rc;
   }
@@ -314,6 +315,28 @@ static bool make_pair_unit(const MiptTriangle& A, const MiptTriangle& B, ScanUni
   u.kB = 7.62939453125e-06f * 4.0f * emax;
   u.emax = emax;
   u.qc = (float)(1.0 / area_ratio); u.qu = (float)qu; u.qv = (float)qv;
+  // A plane normal to a coordinate axis (both frame edges and the far vertex have an exactly zero
+  // component there) is stored in the axis form of mipt_device.hpp: no cross products in the filter.
+  const char* no_axis = getenv("MIPT_NO_AXIS_UNITS");  // developer switch
+  if (no_axis && no_axis[0] == '1') return true;
+  for (int k = 0; k < 3; ++k) {
+    if (!(f1[k] == 0.0f && f2[k] == 0.0f && q[k] - r[k] == 0.0f)) continue;
+    const int i = (k + 1) % 3, j = (k + 2) % 3;
+    const double D = F1[i] * F2[j] - F1[j] * F2[i];
+    const double up = 1.0 + 9.5367431640625e-07;  // the bound factors are rounded up
+    const float kA = (float)((double)u.kA / std::fabs(D) * up), kB = (float)((double)u.kB / std::fabs(D) * up);
+    const float kT = (float)((double)u.kA * 0.0625 / std::fabs(D) * up);
+    if (!(std::isfinite(kA) && std::isfinite(kB) && std::isfinite(kT) && kA > 0.f && kT > 0.f)) break;
+    u.e1x = (float)(F2[j] / D); u.e1y = (float)(-F2[i] / D);
+    u.e1z = (float)(-F1[j] / D); u.e2x = (float)(F1[i] / D);
+    u.e2y = kT;
+    const uint32_t axis = (uint32_t)k;
+    memcpy(&u.e2z, &axis, 4);
+    u.v0x = r[k]; u.v0y = r[i]; u.v0z = r[j];  // permuted like the ray will be
+    u.kA = kA; u.kB = kB;
+    u.meta = 0x80000000u;  // marks the axis form for build_scan_units (which sets meta afterwards)
+    break;
+  }
   return true;
 }
 
@@ -329,23 +352,25 @@ static void make_single_unit(const TriRec& t, ScanUnit& u) {
 // `ids` lists the triangles to cover, ascending (all of them for a linear-scan scene, the big ones
 // of a tree scene); mask bit p of chunk c stands for triangle ids[32 c + p].
 static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>& tr, const std::vector<int>& ids,
-                             std::vector<ScanUnit>& units, uint32_t& n_pair_units) {
+                             std::vector<ScanUnit>& units, uint32_t& n_pair_units, uint32_t& n_axis_units) {
   const size_t n = ids.size();
   const size_t n_chunks = (n + 31) / 32;
   units.assign(n_chunks * 32 + 1, ScanUnit{});
   n_pair_units = 0;
+  n_axis_units = 0;
   const char* no_pairs = getenv("MIPT_NO_PAIRS");  // developer switch: every triangle its own unit
   const bool pairing = !(no_pairs && no_pairs[0] == '1');
   for (size_t c = 0; c < n_chunks; ++c) {
     const size_t lo = c * 32, hi = std::min(n, lo + 32);
-    std::vector<ScanUnit> pairs, singles;
+    std::vector<ScanUnit> axis_pairs, pairs, singles;
     for (size_t p = lo; p < hi;) {
       ScanUnit u;
       const int i = ids[p];
       if (pairing && p + 1 < hi && ids[p + 1] == i + 1 && std::isfinite(tr[i].kA) && std::isfinite(tr[i + 1].kA) &&
           make_pair_unit(tris[i], tris[i + 1], u)) {
+        const bool axis_form = u.meta == 0x80000000u;
         u.meta = (uint32_t)(p - lo) | ((uint32_t)(p + 1 - lo) << 5);
-        pairs.push_back(u);
+        (axis_form ? axis_pairs : pairs).push_back(u);
         p += 2;
       } else {
         make_single_unit(tr[i], u);
@@ -355,10 +380,16 @@ static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>
       }
     }
     size_t k = lo;
+    std::stable_sort(axis_pairs.begin(), axis_pairs.end(), [](const ScanUnit& x, const ScanUnit& y) {
+      uint32_t ax, ay; memcpy(&ax, &x.e2z, 4); memcpy(&ay, &y.e2z, 4); return ax < ay; });
+    for (const ScanUnit& u : axis_pairs) units[k++] = u;
     for (const ScanUnit& u : pairs) units[k++] = u;
     for (const ScanUnit& u : singles) units[k++] = u;
-    units[lo].meta |= ((uint32_t)pairs.size() << 16) | ((uint32_t)(pairs.size() + singles.size()) << 24);
-    n_pair_units += (uint32_t)pairs.size();
+    const size_t all_pairs = axis_pairs.size() + pairs.size();
+    units[lo].meta |= ((uint32_t)axis_pairs.size() << 10) | ((uint32_t)all_pairs << 16) |
+                      ((uint32_t)(all_pairs + singles.size()) << 24);
+    n_pair_units += (uint32_t)all_pairs;
+    n_axis_units += (uint32_t)axis_pairs.size();
   }
 }
 
@@ -455,7 +486,7 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
   std::vector<ScanUnit> units;
   std::vector<int> all(n_tris);
   for (size_t i = 0; i < n_tris; ++i) all[i] = (int)i;
-  build_scan_units(tris, tr, all, units, s->n_pair_units);
+  build_scan_units(tris, tr, all, units, s->n_pair_units, s->n_axis_units);
   return upload_scan_units(s, units);
 }
 
@@ -505,6 +536,7 @@ static inline unsigned batch_grid(size_t n_rays) {
 }
 
 extern "C" int mipt_scene_pair_units(MiptScene* s) { return s ? (int)s->n_pair_units : 0; }
+extern "C" int mipt_scene_axis_pair_units(MiptScene* s) { return s ? (int)s->n_axis_units : 0; }
 
 extern "C" int mipt_closest_hit_dev(MiptScene* s, const float* d_origin4, const float* d_dir4, size_t n_rays,
                                     int32_t* d_tri_idx, float* d_t, float* d_position4, void* stream) {

@@ -74,9 +74,18 @@ struct __attribute__((aligned(64))) ScanUnit {
   float kA, kB;      // error-bound factors as in TriRec, widened for pairs (see build_scan_units)
   float emax;        // pairs: largest |edge|oo of the two triangles (0 for single triangles)
   float qc, qu, qv;  // pairs: the second triangle in the frame of the first
-  uint32_t meta;     // bits 0-4 / 5-9: mask bit of the first / second triangle; 16-23: pairs in
-                     // this chunk; 24-31: units in this chunk (first record of a chunk only)
+  uint32_t meta;     // bits 0-4 / 5-9: mask bit of the first / second triangle; first record of a
+                     // chunk only: 10-15 axis-plane pairs, 16-23 all pairs, 24-31 units in this chunk
 };
+// A pair whose plane is normal to coordinate axis k (f1, f2 and the far vertex have an exactly zero
+// k component: walls, floors, box tops) is stored first in its chunk and in another form, because
+// its system needs no cross products: t = -s_k / d_k, in-plane hit point p = s + t d, and
+// (u, v) = (p_i A + p_j B, p_i C + p_j D) with i, j = the axes after k. Fields reused:
+// e1x, e1y, e1z, e2x = A, B, C, D (the inverse of the 2x2 system, rounded from double);
+// v0 = (r_k, r_i, r_j), permuted like the ray; e2y = kA 2^-4 / |n|; e2z = k (integer bits); kA, kB = the pair's factors divided by
+// |n| = |f1_i f2_j - f1_j f2_i|, so that with |det| = |n| |d_k| the bounds are those of the
+// general form. The evaluation has fewer roundings than the general one and stays inside the same
+// error budget (<= 10 eps S Dm / (|f1| |d_k|) against the 64 eps share of the filter).
 
 struct BvhNode;
 
@@ -451,6 +460,32 @@ __device__ __forceinline__ void unit_candidates(UP U, float ox, float oy, float 
   }
 }
 
+template <typename UP>
+__device__ __forceinline__ void axis_pair_candidates(UP U, float sk, float si, float sj, float dk, float di,
+                                                     float dj, float Dm, uint32_t& mask) {
+#pragma clang fp contract(fast)
+  const float S = fmaxf(fmaxf(fmaxf(fabsf(sk), fabsf(si)), fabsf(sj)), U->emax);
+  const bool well = fabsf(dk) >= Dm * U->kA + 1e-35f;
+  const float inv = __builtin_amdgcn_rcpf(dk);
+  const float t = -(sk * inv);
+  const float pi = si + t * di, pj = sj + t * dj;
+  const float u = pi * U->e1x + pj * U->e1y, v = pi * U->e1z + pj * U->e2x;
+  const float w1 = S * fabsf(inv);
+  const float drel = (w1 * Dm) * U->kB;
+  const float delta = drel + (0.02f / FILTER_TIGHT + 0.002f);
+  const float dt = w1 * U->e2y + 1e-30f;
+  const bool behind = t < -dt;
+  const float uv = u + v;
+  const bool outA = (u < -delta) | (v < -delta) | (uv > 1.001f + 2.0f * delta) | behind;
+  const uint32_t meta = U->meta;
+  if (!(well & outA)) mask |= 1u << (meta & 31u);
+  const float lq = (uv - 1.0f) * U->qc;
+  const float l1 = u - U->qu * lq, l2 = v - U->qv * lq;
+  const float dB = drel * 9.0f + (0.05f / FILTER_TIGHT + 0.01f);
+  const bool outB = (lq < -dB) | (l1 < -dB) | (l2 < -dB) | behind;
+  if (!(well & outB)) mask |= 1u << ((meta >> 5) & 31u);
+}
+
 // Phase 1 over one chunk of scan units (records [0, n_units) at `chunk`, pairs first): the mask of
 // the chunk's triangles the reference could accept. Unrolled so that the scalar loads of the next
 // record overlap the arithmetic of this one (rolled, every unit waits out its own load: -9 %).
@@ -458,9 +493,35 @@ __device__ __forceinline__ uint32_t unit_mask(const ScanUnit* chunk, V4 o, V4 d,
   const ScanUnit MIPT_CONST* units = as_constant(chunk);
   const uint32_t counts = units[0].meta >> 16;
   const int n_pairs = (int)(counts & 0xFFu), n_units = (int)(counts >> 8);
+  const int n_axis = (int)((units[0].meta >> 10) & 0x3Fu);
   uint32_t mask = 0;
+  // axis-plane pairs come sorted by axis; the ray is permuted once per run of equal axes.
+  // (Rolled: unrolled by 2 or 4 the kernel spills registers; requesting the next record before
+  // this one is evaluated costs more in register copies than the wait it hides.)
+  uint32_t cur = 3u;
+  float ok = 0.f, oi = 0.f, oj = 0.f, dk = 0.f, di = 0.f, dj = 0.f;
+#pragma unroll 1
+  for (int k = 0; k < n_axis; ++k) {
+    // every field read up front: one scalar load of the whole record, axis included
+    const ScanUnit MIPT_CONST* U = units + k;
+    ScanUnit R;
+    R.v0x = U->v0x; R.v0y = U->v0y; R.v0z = U->v0z; R.e1x = U->e1x; R.e1y = U->e1y; R.e1z = U->e1z;
+    R.e2x = U->e2x; R.e2y = U->e2y; R.e2z = U->e2z; R.kA = U->kA; R.kB = U->kB; R.emax = U->emax;
+    R.qc = U->qc; R.qu = U->qu; R.qv = U->qv; R.meta = U->meta;
+    const uint32_t axis = __float_as_uint(R.e2z);  // wave-uniform
+    if (axis != cur) {
+      cur = axis;
+      ok = axis == 0u ? o.x : axis == 1u ? o.y : o.z;
+      oi = axis == 0u ? o.y : axis == 1u ? o.z : o.x;
+      oj = axis == 0u ? o.z : axis == 1u ? o.x : o.y;
+      dk = axis == 0u ? d.x : axis == 1u ? d.y : d.z;
+      di = axis == 0u ? d.y : axis == 1u ? d.z : d.x;
+      dj = axis == 0u ? d.z : axis == 1u ? d.x : d.y;
+    }
+    axis_pair_candidates(&R, ok - R.v0x, oi - R.v0y, oj - R.v0z, dk, di, dj, Dm, mask);
+  }
 #pragma unroll 4
-  for (int k = 0; k < n_pairs; ++k)
+  for (int k = n_axis; k < n_pairs; ++k)
     unit_candidates<true>(units + k, o.x, o.y, o.z, d.x, d.y, d.z, Dm, mask);
 #pragma unroll 4
   for (int k = n_pairs; k < n_units; ++k)

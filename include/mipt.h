@@ -194,6 +194,10 @@ int mipt_scene_has_bvh(MiptScene* scene, uint64_t* n_nodes, double* build_ms);
  * halves of a wall or box face, TestModelH.h:87-160) the candidate filter treats as one unit.
  * Purely an optimisation of the filter; every candidate still goes through the reference's test. */
 int mipt_scene_pair_units(MiptScene* scene);
+/* ... and how many of those pairs lie in a plane normal to a coordinate axis (walls, floors, box
+ * tops): the filter solves their ray/plane system without cross products. No counterpart in the
+ * reference either. */
+int mipt_scene_axis_pair_units(MiptScene* scene);
 void mipt_scene_destroy(MiptScene* scene);
 
 /* Batch closestIntersection (intersections.cpp:6-55). Host pointers.

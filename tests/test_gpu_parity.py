@@ -269,10 +269,12 @@ def test_fog_matches_oracle_statistically(api, O, pkg):
     assert frac_paths > 0.999, frac_paths
 
 
-def quad_scene(O, dtype, n_quads, seed):
+def quad_scene(O, dtype, n_quads, seed, axis_planes=False):
     """Random planar quads split into two triangles with every vertex labelling, next to each other
     in index order: parallelograms, general convex quads, thin ones, at scales 1e-3 .. 1; plus
-    near-pairs that must NOT merge (bent quads, triangles sharing only a vertex)."""
+    near-pairs that must NOT merge (bent quads, triangles sharing only a vertex). With axis_planes
+    every quad lies in a plane normal to a coordinate axis (one coordinate exactly constant), half
+    of them with edges along the other two axes, half turned within the plane."""
     import bigscenes
     rng = np.random.default_rng(seed)
     v0s, v1s, v2s = [], [], []
@@ -281,6 +283,17 @@ def quad_scene(O, dtype, n_quads, seed):
         size = 10 ** rng.uniform(-3, 0)
         a = rng.normal(size=3); a /= np.linalg.norm(a)
         b = rng.normal(size=3); b -= a * (a @ b); b /= np.linalg.norm(b)
+        if axis_planes:
+            ax = k % 3
+            i, j = (ax + 1) % 3, (ax + 2) % 3
+            phi = 0.0 if (k // 3) % 2 == 0 else rng.uniform(0, 2 * np.pi)
+            a = np.zeros(3); b = np.zeros(3)
+            a[i], a[j] = np.cos(phi), np.sin(phi)
+            b[i], b[j] = -np.sin(phi), np.cos(phi)
+            if phi == 0.0:
+                a[j] = 0.0; b[i] = 0.0
+            if k % 5 == 0:
+                a = -a   # both orientations of the frame
         aspect = 10 ** rng.uniform(-1.5, 0)
         P = [c, c + a * size, c + a * size + b * size * aspect, c + b * size * aspect]   # parallelogram
         kind = k % 4
@@ -300,13 +313,32 @@ def quad_scene(O, dtype, n_quads, seed):
 
 
 def test_cornell_walls_are_filtered_as_pairs(api, O):
-    # GlassCube: 5 walls, 5 faces of the block, the mirror = 11 pairs of 22 triangles
+    # GlassCube: 5 walls, 5 faces of the block, the mirror = 11 pairs of 22 triangles; the walls
+    # and the block's top lie in axis planes
     sc = api.Scene(O.load_test_model(2))
     assert sc.pair_units() == 11
+    assert 6 <= sc.axis_pair_units() <= 7
     sc.close()
     sc = api.Scene(O.load_test_model(0))
     assert sc.pair_units() >= 13   # 5 walls + 4 side faces of each block (their tops are no parallelograms)
+    assert sc.axis_pair_units() >= 5
     sc.close()
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_axis_plane_pairs_equal_literal_scan(api, O, pkg, seed):
+    # quads in planes normal to a coordinate axis take the filter's axis form (no cross products)
+    tris = quad_scene(O, pkg.abi.TRIANGLE_DTYPE, 60, seed, axis_planes=True)
+    sc = api.Scene(tris)
+    assert sc.axis_pair_units() >= 20
+    _, _, closest_bad, any_bad = sc.selfcheck(1 << 26, seed=seed)
+    assert (closest_bad, any_bad) == (0, 0)
+    o, d = raygen.surface_rays(tris, 1 << 14, seed=seed)
+    idx, t, pos = sc.closest_hit(o, d)
+    sc.close()
+    oidx, ot, opos = O.closest_hit(tris, None, o, d)
+    assert np.array_equal(idx, oidx)
+    assert np.array_equal(bits(t[idx >= 0]), bits(ot[oidx >= 0]))
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
