@@ -54,6 +54,9 @@ struct __attribute__((aligned(64))) BvhBin {
 #ifndef MIPT_BVH_QUANT
 #define MIPT_BVH_QUANT 1
 #endif
+#ifndef MIPT_BVH_GREEDY
+#define MIPT_BVH_GREEDY 1
+#endif
 #if MIPT_BVH_QUANT
 // 64 bytes: the children's boxes on a per-node grid of 256 steps per axis. A bound is
 // org[axis] + q * 2^(e[axis] - 127), decoded with one fused multiply-add; the build rounds lower
@@ -232,23 +235,45 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_collapse(const BvhBin* __restrict
   const BvhBin B = bin[b];
   int ref[4];
   float lo[4][3], hi[4][3];
-  int m = 0;
-  for (int side = 0; side < 2; ++side) {
-    const int c = side ? B.right : B.left;
-    if (c >= 0) {
-      const BvhBin C = bin[c];
-      ref[m] = C.left;
-      for (int k = 0; k < 3; ++k) { lo[m][k] = C.lmin[k]; hi[m][k] = C.lmax[k]; }
+  ref[0] = B.left; ref[1] = B.right;
+  for (int k = 0; k < 3; ++k) { lo[0][k] = B.lmin[k]; hi[0][k] = B.lmax[k]; lo[1][k] = B.rmin[k]; hi[1][k] = B.rmax[k]; }
+  int m = 2;
+#if MIPT_BVH_GREEDY
+  // open the inner child with the largest surface until the node has four children (or only leaves)
+  while (m < 4) {
+    int pick = -1;
+    float best = -1.f;
+    for (int c = 0; c < m; ++c) {
+      if (ref[c] < 0) continue;
+      const float dx = hi[c][0] - lo[c][0], dy = hi[c][1] - lo[c][1], dz = hi[c][2] - lo[c][2];
+      const float area = dx * dy + dy * dz + dz * dx;
+      if (pick < 0 || area > best) { pick = c; best = area; }
+    }
+    if (pick < 0) break;
+    const BvhBin C = bin[ref[pick]];
+    ref[pick] = C.left;
+    ref[m] = C.right;
+    for (int k = 0; k < 3; ++k) { lo[pick][k] = C.lmin[k]; hi[pick][k] = C.lmax[k]; lo[m][k] = C.rmin[k]; hi[m][k] = C.rmax[k]; }
+    ++m;
+  }
+#else
+  // both children give way to their own children
+  {
+    const int l = B.left, r = B.right;
+    if (r >= 0) {
+      const BvhBin C = bin[r];
+      ref[1] = C.left; ref[m] = C.right;
+      for (int k = 0; k < 3; ++k) { lo[1][k] = C.lmin[k]; hi[1][k] = C.lmax[k]; lo[m][k] = C.rmin[k]; hi[m][k] = C.rmax[k]; }
       ++m;
-      ref[m] = C.right;
-      for (int k = 0; k < 3; ++k) { lo[m][k] = C.rmin[k]; hi[m][k] = C.rmax[k]; }
-      ++m;
-    } else {
-      ref[m] = c;
-      for (int k = 0; k < 3; ++k) { lo[m][k] = side ? B.rmin[k] : B.lmin[k]; hi[m][k] = side ? B.rmax[k] : B.lmax[k]; }
+    }
+    if (l >= 0) {
+      const BvhBin C = bin[l];
+      ref[0] = C.left; ref[m] = C.right;
+      for (int k = 0; k < 3; ++k) { lo[0][k] = C.lmin[k]; hi[0][k] = C.lmax[k]; lo[m][k] = C.rmin[k]; hi[m][k] = C.rmax[k]; }
       ++m;
     }
   }
+#endif
   BvhNode N;
   // the inner children get consecutive slots: siblings a ray visits together share lines
   int n_inner = 0;
