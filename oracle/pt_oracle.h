@@ -20,9 +20,13 @@
  * centre-pixel hit distance bit pattern and the exact whole-frame counts of
  * closestIntersection / existsIntersection / bounce* / glm::determinant /
  * glm::inverse calls for four (scene, size) frames, all reproduced exactly by
- * MIPT_RNG_MINSTD_GLOBAL renders of this file. Radiance VALUES have no
- * reference vector in this image: per-path colour is "parity unpinned" beyond
- * that branch-level agreement. Fog has no reference code at all.
+ * MIPT_RNG_MINSTD_GLOBAL renders of this file. Radiance VALUES are pinned at
+ * image level by the reference's own rendering of its glassWolf scene
+ * (CW/raytracer/screenshot.bmp, kept as tests/golden/glasswolf_screen_500x500.npz):
+ * this file's paths through the diffuse room reproduce that image's pixel values
+ * to Monte-Carlo noise (tests/test_reference_screenshot.py). Per-path bit patterns
+ * have no reference vector in this image. Fog has no reference code at all:
+ * "parity unpinned".
  *
  * Arithmetic: build with -O2 -ffp-contract=off (see Makefile); every float
  * product and sum is rounded separately, as in the reference compiled without
