@@ -239,8 +239,8 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
 }
 
 // Batch queries against a tree scene: persistent lanes that draw rays from a queue, so a lane whose
-// walk is over takes the next ray while its neighbours finish theirs (bvh_burst returns once half
-// the wave is done). SHADOW = existsIntersection, else closestIntersection incl. the spheres.
+// walk is over takes the next ray while its neighbours finish theirs (bvh_burst returns once
+// most of the wave is done). SHADOW = existsIntersection, else closestIntersection incl. the spheres.
 #ifndef MIPT_BATCH_RESERVE
 #define MIPT_BATCH_RESERVE 128
 #endif
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
     }
     prof.mark(PF_QUEUE);
     // A lane is `ready` for shading when its scene query has an answer. The linear scan answers
-    // within the iteration; a walk through the tree may span several (bvh_burst returns when half
+    // within the iteration; a walk through the tree may span several (bvh_burst returns when most
     // of the walking lanes are done, so finished lanes shade and start their next ray instead of
     // waiting for the longest walk of the wave).
     bool ready = false;
