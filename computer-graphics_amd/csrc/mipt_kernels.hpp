@@ -168,7 +168,7 @@ __device__ __forceinline__ void scene_query(const DeviceScene& sc, V4 o, V4 d, b
   BvhTrav T;
   BvhMem M;
   bvh_begin(T, M, sc, r, shadow, h.lim);
-  while (T.cur != BVH_DONE) bvh_burst(T, M, sc, sc.bvh, r, shadow, h.lim, overflow);
+  while (T.cur != BVH_DONE) bvh_burst(T, M, StackScratch{M.stack}, sc, sc.bvh, r, shadow, h.lim, overflow);
   if (T.redo) {
     redo++;
     bvh_closest_exhaustive(sc, sc.bvh, r, h, overflow);
@@ -264,8 +264,10 @@ __global__ __launch_bounds__(BLOCK) MIPT_BATCH_OCC void k_bvh_batch(DeviceScene 
                                                      int32_t* __restrict__ tri_idx, float* __restrict__ t_out,
                                                      float4* __restrict__ pos_out, uint8_t* __restrict__ occluded) {
   const int lane = threadIdx.x & 63;
+  __shared__ int lds_stack[(BVH_LDS_STACK ? BVH_LDS_STACK : 1) * BLOCK];
   BvhTrav T;
   BvhMem M;
+  const StackLds stk{lds_stack + threadIdx.x, M.stack};
   T.cur = BVH_DONE;
   BvhRay r = {};
   unsigned long long my = 0;
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_BATCH_OCC void k_bvh_batch(DeviceScene 
     }
     if (!__any(have)) break;  // every lane idle: the queue has run dry
     if (have) {
-      bvh_burst(T, M, sc, sc.bvh, r, SHADOW, lim0, overflow);
+      bvh_burst(T, M, stk, sc, sc.bvh, r, SHADOW, lim0, overflow);
       if (T.cur == BVH_DONE) {
         HitAcc h;
         h.set_lim(lim0);
@@ -372,9 +374,11 @@ __global__ __launch_bounds__(BLOCK) MIPT_BATCH_OCC void k_bvh_batch(DeviceScene 
 #ifndef MIPT_WAVES_PER_EU
 #define MIPT_WAVES_PER_EU 5
 #endif
-// tree scenes are bound by the latency of dependent node fetches; measured best of 4, 5, 6
+// tree scenes: the walk's stack takes 12 KB of LDS per workgroup on top of the path state, which
+// fits four workgroups per CU; 128 registers per lane then leave the kernel without spills
+// (measured best of 3, 4, 5)
 #ifndef MIPT_TREE_WAVES_PER_EU
-#define MIPT_TREE_WAVES_PER_EU 5
+#define MIPT_TREE_WAVES_PER_EU 4
 #endif
 #define MIPT_PATHS_OCC                                                                              \
   __attribute__((amdgpu_waves_per_eu(KIND == SCENE_BVH ? MIPT_TREE_WAVES_PER_EU : MIPT_WAVES_PER_EU, \
@@ -432,6 +436,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   constexpr bool BVH = KIND == SCENE_BVH;
   BvhTrav trav;      // tree scenes: the lane's walk, resumable across iterations of the main loop
   BvhMem trav_mem;
+  __shared__ int bvh_lds_stack[(BVH && BVH_LDS_STACK ? BVH_LDS_STACK : 0) * BLOCK + 1];
   trav.cur = BVH_DONE;
   bool walking = false;
   // per-primitive records the shading reads by hit index: from LDS for small scenes
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
     if (BVH) {
       BvhRay r = bvh_ray(a.sc, o, d);  // o, d stay put while the lane walks
       if (!walking) { bvh_begin(trav, trav_mem, a.sc, r, shadow, lim0); walking = true; }
-      bvh_burst(trav, trav_mem, a.sc, a.sc.bvh, r, shadow, lim0, overflow);
+      bvh_burst(trav, trav_mem, StackLds{bvh_lds_stack + tid, trav_mem.stack}, a.sc, a.sc.bvh, r, shadow, lim0, overflow);
       n_tests = r.n_leaves; n_nodes = r.n_nodes;
       if (trav.cur == BVH_DONE) {
         walking = false;
