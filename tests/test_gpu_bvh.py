@@ -195,3 +195,40 @@ def test_tree_scene_with_sphere_and_all_materials(api, O, dtype):
     for k in ("closest_rays", "shadow_rays", "diffuse_bounces", "mirror_bounces", "glass_bounces", "sphere_tests"):
         assert getattr(st, k) == getattr(ost, k), k
     assert (bits(img) == bits(ref)).all(axis=2).mean() > 0.99
+
+
+def test_stacked_sheets_need_a_deep_stack(api, O, dtype):
+    # 1500 parallel sheets (3000 triangles) 0.0005 apart, every one as large as the scene: all
+    # boxes overlap, a ray across the stack enters every node it meets, each four-wide node pushes
+    # up to three entries -- the walk's stack grows past the part that lives in LDS
+    rng = np.random.default_rng(11)
+    n = 1500
+    z = (-0.4 + 0.0005 * np.arange(n)).astype(np.float32)
+    order = rng.permutation(n)  # index order unrelated to depth order
+    v0s, v1s, v2s = [], [], []
+    for k in order:
+        a = np.array([-0.8, -0.8, z[k]]); b = np.array([0.8, -0.8, z[k]])
+        c = np.array([0.8, 0.8, z[k]]); d = np.array([-0.8, 0.8, z[k]])
+        v0s += [a, a]; v1s += [b, c]; v2s += [c, d]
+    m = len(v0s)
+    color = rng.uniform(0.2, 0.9, (m, 3)).astype(np.float32)
+    tris = bigscenes._finish(dtype, np.array(v0s), np.array(v1s), np.array(v2s), color, np.zeros(m, dtype=np.uint32))
+    sc = api.Scene(tris)
+    assert sc.bvh_info()[0]
+    _, _, closest_bad, any_bad = sc.selfcheck(1 << 18, seed=3)
+    assert (closest_bad, any_bad) == (0, 0)
+    assert sc.last_selfcheck_bvh[1] == 0  # no stack overflow
+    # rays across the stack from both sides, and steep ones that cross only a part of it
+    k = 1 << 12
+    o = np.ones((k, 4), dtype=np.float32)
+    o[:, :2] = rng.uniform(-0.7, 0.7, (k, 2))
+    o[:, 2] = np.where(np.arange(k) % 2 == 0, -0.9, 0.9)
+    d = np.zeros((k, 4), dtype=np.float32)
+    d[:, :2] = rng.normal(scale=0.3, size=(k, 2))
+    d[:, 2] = -np.sign(o[:, 2])
+    idx, t, pos = sc.closest_hit(o, d)
+    sc.close()
+    oidx, ot, opos = O.closest_hit(tris, None, o, d)
+    assert np.array_equal(idx, oidx)
+    assert np.array_equal(bits(t[oidx >= 0]), bits(ot[oidx >= 0]))
+    assert (oidx >= 0).mean() > 0.5
