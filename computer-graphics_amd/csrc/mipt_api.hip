@@ -468,7 +468,9 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
   HIP_TRY(hipMalloc(&s->d_shade, sh.size() * sizeof(ShadeRec)));
   HIP_TRY(hipMalloc(&s->d_spheres, sp.size() * sizeof(SphereRec)));
   HIP_TRY(hipMalloc(&s->d_stats, (ST_COUNT + PF_COUNT) * sizeof(unsigned long long)));
-  HIP_TRY(hipMalloc(&s->d_queue, 256));
+  // 256 bytes for the path kernel's queue head, then BATCH_HEADS heads of the batch kernels' queue,
+  // one 128-byte line each
+  HIP_TRY(hipMalloc(&s->d_queue, 256 + BATCH_HEADS * 128));
   HIP_TRY(hipMemcpy(s->d_tris, tr.data(), tr.size() * sizeof(TriRec), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s->d_shade, sh.data(), sh.size() * sizeof(ShadeRec), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s->d_spheres, sp.data(), sp.size() * sizeof(SphereRec), hipMemcpyHostToDevice));
@@ -546,8 +548,8 @@ extern "C" int mipt_closest_hit_dev(MiptScene* s, const float* d_origin4, const 
   if (n_rays > ((size_t)1 << 31) * BLOCK) return fail(MIPT_E_INVALID, "mipt_closest_hit: too many rays");
   HIP_TRY(hipSetDevice(s->device));
   if (s->d.bvh) {
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(s->d_queue) + 2;
-    HIP_TRY(hipMemsetAsync(q, 0, 8, (hipStream_t)stream));
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(s->d_queue) + 32;
+    HIP_TRY(hipMemsetAsync(q, 0, BATCH_HEADS * 128, (hipStream_t)stream));
     hipLaunchKernelGGL(k_bvh_batch<false>, dim3(batch_grid(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
                        (const float4*)d_origin4, (const float4*)d_dir4, (const float*)nullptr,
                        (unsigned long long)n_rays, q, d_tri_idx, d_t, (float4*)d_position4, (uint8_t*)nullptr);
@@ -567,8 +569,8 @@ extern "C" int mipt_any_hit_dev(MiptScene* s, const float* d_origin4, const floa
   if (n_rays > ((size_t)1 << 31) * BLOCK) return fail(MIPT_E_INVALID, "mipt_any_hit: too many rays");
   HIP_TRY(hipSetDevice(s->device));
   if (s->d.bvh) {
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(s->d_queue) + 2;
-    HIP_TRY(hipMemsetAsync(q, 0, 8, (hipStream_t)stream));
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(s->d_queue) + 32;
+    HIP_TRY(hipMemsetAsync(q, 0, BATCH_HEADS * 128, (hipStream_t)stream));
     hipLaunchKernelGGL(k_bvh_batch<true>, dim3(batch_grid(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
                        (const float4*)d_origin4, (const float4*)d_dir4, d_max_t, (unsigned long long)n_rays, q,
                        (int32_t*)nullptr, (float*)nullptr, (float4*)nullptr, d_occluded);

@@ -245,6 +245,10 @@ __global__ __launch_bounds__(BLOCK) void k_any_hit(DeviceScene sc, const float4*
 #define MIPT_BATCH_RESERVE 128
 #endif
 constexpr unsigned long long BATCH_RESERVE = MIPT_BATCH_RESERVE;
+#ifndef MIPT_BATCH_HEADS
+#define MIPT_BATCH_HEADS 16
+#endif
+constexpr int BATCH_HEADS = MIPT_BATCH_HEADS;  // queue heads of the batch kernels, 128 bytes apart
 
 // measured best of 5..8 waves per SIMD with the vote-scheduled walk (8: spills, 6: ties on the largest scenes)
 #ifndef MIPT_BATCH_WAVES
@@ -275,21 +279,29 @@ __global__ __launch_bounds__(BLOCK) MIPT_BATCH_OCC void k_bvh_batch(DeviceScene 
   bool have = false, drained = false;
   uint32_t overflow = 0;
   unsigned long long res_next = 0, res_end = 0;  // wave-uniform: the wave's reserved run of rays
+  const unsigned long long per_head = (n_rays + BATCH_HEADS - 1) / BATCH_HEADS;
+  int head = (int)(blockIdx.x % BATCH_HEADS), heads_done = 0;  // wave-uniform
   for (;;) {
     const unsigned long long need = __ballot(!have);
     if (need && !drained) {
-      // the wave reserves BATCH_RESERVE rays with one atomic and hands them to its lanes as they
-      // run dry (one atomic per handful of rays made the queue head the bottleneck of the kernel)
-      if (res_next == res_end) {
+      // The wave reserves BATCH_RESERVE rays with one atomic and hands them to its lanes as they
+      // run dry. The rays are split into BATCH_HEADS contiguous parts, each with its own queue head (one
+      // head took 50 M same-address atomics per second on fast scenes and was the bottleneck); a
+      // wave starts at the part its workgroup index picks and moves on when a part has run dry.
+      while (res_next == res_end && !drained) {
+        const unsigned long long lo = (unsigned long long)head * per_head;
+        const unsigned long long hi = lo + per_head < n_rays ? lo + per_head : n_rays;
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(queue, (unsigned long long)BATCH_RESERVE);
+        if (lane == 0 && lo < hi) base = atomicAdd(queue + head * 16, (unsigned long long)BATCH_RESERVE);
         base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
                (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)base);
-        if (base >= n_rays) {
-          drained = true;
+        base += lo;
+        if (lo >= hi || base >= hi) {
+          head = head + 1 == BATCH_HEADS ? 0 : head + 1;
+          if (++heads_done == BATCH_HEADS) drained = true;
         } else {
           res_next = base;
-          res_end = base + BATCH_RESERVE < n_rays ? base + BATCH_RESERVE : n_rays;
+          res_end = base + BATCH_RESERVE < hi ? base + BATCH_RESERVE : hi;
         }
       }
       if (!drained) {
