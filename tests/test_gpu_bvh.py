@@ -232,3 +232,19 @@ def test_stacked_sheets_need_a_deep_stack(api, O, dtype):
     assert np.array_equal(idx, oidx)
     assert np.array_equal(bits(t[oidx >= 0]), bits(ot[oidx >= 0]))
     assert (oidx >= 0).mean() > 0.5
+
+
+def test_tree_batches_of_any_size(api, O, dtype):
+    # batches smaller than the number of queue heads, smaller than a wave, not a multiple of anything
+    tris = scenes(O, dtype)["mesh9k"]
+    sc = api.Scene(tris)
+    o_all, d_all = raygen.interior_rays(5000, seed=21)
+    so, sd, sr = raygen.shadow_rays(tris, 5000, seed=22)
+    for n in (1, 5, 17, 63, 64, 65, 1000, 4999):
+        idx, t, pos = sc.closest_hit(o_all[:n], d_all[:n])
+        oidx, ot, opos = O.closest_hit(tris, None, o_all[:n], d_all[:n])
+        assert np.array_equal(idx, oidx), n
+        assert np.array_equal(bits(t[oidx >= 0]), bits(ot[oidx >= 0])), n
+        occ = sc.any_hit(so[:n], sd[:n], sr[:n])
+        assert np.array_equal(occ, O.any_hit(tris, so[:n], sd[:n], sr[:n])), n
+    sc.close()
