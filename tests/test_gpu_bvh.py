@@ -195,6 +195,15 @@ def test_tree_scene_with_sphere_and_all_materials(api, O, dtype):
     for k in ("closest_rays", "shadow_rays", "diffuse_bounces", "mirror_bounces", "glass_bounces", "sphere_tests"):
         assert getattr(st, k) == getattr(ost, k), k
     assert (bits(img) == bits(ref)).all(axis=2).mean() > 0.99
+    # the largest LDS footprint the path kernel can ask for: tree scene + sphere + maximum depth
+    sc = api.Scene(tris, sph)
+    p = api.default_params(W, H, flags=1, seed=3, max_depth=16, rr_prob=0.02)
+    img = sc.render_accumulate(cam, light, p, 0, 4)
+    st = sc.stats()
+    sc.close()
+    ref, ost = O.render_accumulate(tris, sph, cam, light, p, 0, 4)
+    assert st.closest_rays == ost.closest_rays and st.shadow_rays == ost.shadow_rays
+    assert (bits(img) == bits(ref)).all(axis=2).mean() > 0.99
 
 
 def test_stacked_sheets_need_a_deep_stack(api, O, dtype):
