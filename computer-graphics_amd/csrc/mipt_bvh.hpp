@@ -633,7 +633,7 @@ __device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, const DeviceSce
 // OR over the triangles, the walk stops at the first acceptance.
 // Returns when the lane's walk is done or when fewer than BVH_KEEP_NUM / BVH_KEEP_DEN of the lanes
 // that entered are still walking.
-template <typename STK>
+template <int KEEP_NUM = BVH_KEEP_NUM, int KEEP_DEN = BVH_KEEP_DEN, typename STK>
 __device__ __forceinline__ void bvh_burst(BvhTrav& T, BvhMem& M, const STK& stack, const DeviceScene& sc,
                                           const BvhNode* __restrict__ nodes, BvhRay& r, bool shadow, float max_t,
                                           uint32_t& overflow) {
@@ -665,7 +665,7 @@ __device__ __forceinline__ void bvh_burst(BvhTrav& T, BvhMem& M, const STK& stac
     }
     if (T.cur == BVH_DONE && T.pend != BVH_DONE) { T.cur = T.pend; T.pend = BVH_DONE; }
     // lanes still walking (this ballot is taken by the lanes inside the loop only)
-    if (BVH_KEEP_DEN * (int)__popcll(__ballot(T.cur != BVH_DONE)) < BVH_KEEP_NUM * entered) break;
+    if (KEEP_DEN * (int)__popcll(__ballot(T.cur != BVH_DONE)) < KEEP_NUM * entered) break;
   }
 }
 

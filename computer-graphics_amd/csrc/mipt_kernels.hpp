@@ -321,7 +321,8 @@ __global__ __launch_bounds__(BLOCK) MIPT_BATCH_OCC void k_bvh_batch(DeviceScene 
     }
     if (!__any(have)) break;  // every lane idle: the queue has run dry
     if (have) {
-      bvh_burst(T, M, stk, sc, sc.bvh, r, SHADOW, lim0, overflow);
+      // refills are cheap here (two loads and the big-triangle filter): leave the walk when half is done
+      bvh_burst<1, 2>(T, M, stk, sc, sc.bvh, r, SHADOW, lim0, overflow);
       if (T.cur == BVH_DONE) {
         HitAcc h;
         h.set_lim(lim0);
