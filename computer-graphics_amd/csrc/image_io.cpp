@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "../../include/mipt.h"
@@ -20,7 +21,7 @@ void put16(std::vector<uint8_t>& b, uint16_t v) { b.push_back((uint8_t)v); b.pus
 void put32(std::vector<uint8_t>& b, uint32_t v) { put16(b, (uint16_t)v); put16(b, (uint16_t)(v >> 16)); }
 }  // namespace
 
-extern "C" int mipt_save_bmp(const char* path, const uint32_t* screen_buffer, int width, int height) {
+static int save_bmp_impl(const char* path, const uint32_t* screen_buffer, int width, int height) {
   if (!path || !screen_buffer) return mipt_internal_fail(MIPT_E_INVALID, "mipt_save_bmp: null argument");
   if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
     return mipt_internal_fail(MIPT_E_INVALID, "mipt_save_bmp: image size out of range");
@@ -48,4 +49,15 @@ extern "C" int mipt_save_bmp(const char* path, const uint32_t* screen_buffer, in
     ok = fwrite(screen_buffer + (size_t)y * (size_t)width, 4, (size_t)width, f) == (size_t)width;
   ok = (fclose(f) == 0) && ok;
   return ok ? MIPT_OK : mipt_internal_fail(MIPT_E_INVALID, "mipt_save_bmp: write failed");
+}
+
+// nothing may throw across the C ABI
+extern "C" int mipt_save_bmp(const char* path, const uint32_t* screen_buffer, int width, int height) {
+  try {
+    return save_bmp_impl(path, screen_buffer, width, height);
+  } catch (const std::bad_alloc&) {
+    return mipt_internal_fail(MIPT_E_NOMEM, "mipt_save_bmp: host allocation failed");
+  } catch (...) {
+    return mipt_internal_fail(MIPT_E_INVALID, "mipt_save_bmp: unexpected exception");
+  }
 }

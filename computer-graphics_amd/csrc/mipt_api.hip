@@ -67,6 +67,10 @@ struct MiptScene {
   int n_wide_nodes = 0;
   double bvh_build_ms = 0.0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // recorded after every launch that uses the scene's scratch memory (queue heads, item sums,
+  // counters); the next such launch waits for it, so calls on different streams do not overlap
+  hipEvent_t ev_busy = nullptr;
+  bool busy_valid = false;
   bool timed = false;
   bool stats_valid = false;
   uint64_t last_paths = 0;
@@ -86,10 +90,24 @@ static void scene_free(MiptScene* s) {
   if (s->d_big) (void)hipFree(s->d_big);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->ev_busy) (void)hipEventDestroy(s->ev_busy);
   delete s;
 }
 
 extern "C" void mipt_scene_destroy(MiptScene* s) { scene_free(s); }
+
+// A launch that uses the scene's scratch memory waits for the previous one, whichever stream that
+// ran on, and leaves its own mark behind.
+static int scratch_acquire(MiptScene* s, hipStream_t st) {
+  if (s->busy_valid) HIP_TRY(hipStreamWaitEvent(st, s->ev_busy, 0));
+  return MIPT_OK;
+}
+static int scratch_release(MiptScene* s, hipStream_t st) {
+  HIP_TRY(hipEventRecord(s->ev_busy, st));
+  s->busy_valid = true;
+  return MIPT_OK;
+}
+
 
 // RAII device buffer for temporaries and the host-pointer entry points
 struct DevBuf {
@@ -477,6 +495,7 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
   HIP_TRY(hipMemset(s->d_stats, 0, (ST_COUNT + PF_COUNT) * sizeof(unsigned long long)));
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
+  HIP_TRY(hipEventCreateWithFlags(&s->ev_busy, hipEventDisableTiming));
   s->d.tris = s->d_tris;
   s->d.shade = s->d_shade;
   s->d.spheres = s->d_spheres;
@@ -513,7 +532,14 @@ extern "C" int mipt_scene_create(const MiptTriangle* tris, size_t n_tris, const 
     return fail(MIPT_E_INVALID, "mipt_scene_create: device %d out of range (%d devices)", device, n_dev);
   MiptScene* s = new (std::nothrow) MiptScene();
   if (!s) return fail(MIPT_E_NOMEM, "mipt_scene_create: host allocation failed");
-  int rc = scene_create_impl(tris, n_tris, spheres, n_spheres, device, s);
+  int rc;
+  try {
+    rc = scene_create_impl(tris, n_tris, spheres, n_spheres, device, s);
+  } catch (const std::bad_alloc&) {
+    rc = fail(MIPT_E_NOMEM, "mipt_scene_create: host allocation failed");
+  } catch (...) {
+    rc = fail(MIPT_E_INVALID, "mipt_scene_create: unexpected exception");
+  }
   if (rc != MIPT_OK) { scene_free(s); return rc; }
   *out = s;
   return MIPT_OK;
@@ -549,10 +575,14 @@ extern "C" int mipt_closest_hit_dev(MiptScene* s, const float* d_origin4, const 
   HIP_TRY(hipSetDevice(s->device));
   if (s->d.bvh) {
     unsigned long long* q = reinterpret_cast<unsigned long long*>(s->d_queue) + 32;
+    const int rc = scratch_acquire(s, (hipStream_t)stream);
+    if (rc != MIPT_OK) return rc;
     HIP_TRY(hipMemsetAsync(q, 0, BATCH_HEADS * 128, (hipStream_t)stream));
     hipLaunchKernelGGL(k_bvh_batch<false>, dim3(batch_grid(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
                        (const float4*)d_origin4, (const float4*)d_dir4, (const float*)nullptr,
                        (unsigned long long)n_rays, q, d_tri_idx, d_t, (float4*)d_position4, (uint8_t*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return scratch_release(s, (hipStream_t)stream);
   } else
     hipLaunchKernelGGL(k_closest_hit<false>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
                        (const float4*)d_origin4, (const float4*)d_dir4, n_rays, d_tri_idx, d_t,
@@ -570,10 +600,14 @@ extern "C" int mipt_any_hit_dev(MiptScene* s, const float* d_origin4, const floa
   HIP_TRY(hipSetDevice(s->device));
   if (s->d.bvh) {
     unsigned long long* q = reinterpret_cast<unsigned long long*>(s->d_queue) + 32;
+    const int rc = scratch_acquire(s, (hipStream_t)stream);
+    if (rc != MIPT_OK) return rc;
     HIP_TRY(hipMemsetAsync(q, 0, BATCH_HEADS * 128, (hipStream_t)stream));
     hipLaunchKernelGGL(k_bvh_batch<true>, dim3(batch_grid(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
                        (const float4*)d_origin4, (const float4*)d_dir4, d_max_t, (unsigned long long)n_rays, q,
                        (int32_t*)nullptr, (float*)nullptr, (float4*)nullptr, d_occluded);
+    HIP_TRY(hipGetLastError());
+    return scratch_release(s, (hipStream_t)stream);
   } else
     hipLaunchKernelGGL(k_any_hit<false>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
                        (const float4*)d_origin4, (const float4*)d_dir4, d_max_t, n_rays, d_occluded);
@@ -716,71 +750,110 @@ static void launch_paths(const MiptScene* s, const PathArgs& a, dim3 grid, size_
   }
 }
 
-extern "C" int mipt_render_accumulate_dev(MiptScene* s, const MiptCamera* cam, const MiptLight* light,
-                                          const MiptParams* p, uint32_t sample_begin, uint32_t sample_count,
-                                          float* d_accum_rgb, void* stream) {
+// Scratch of one launch of the path kernel: where the queue head and the per-item sums live.
+struct RenderScratch {
+  uint32_t* queue;
+  float* sums;
+};
+
+// Work items of one call: ITEM_SAMPLES consecutive samples of one pixel, enumerated tile by tile
+// (8x8 pixels) and sample block by sample block; one scratch image per sample block.
+struct RenderShape {
+  uint32_t tiles_x, item_samples, n_sblocks;
+  uint64_t n_slots, n_items;
+  size_t n_img, sums_bytes;
+};
+
+static int render_shape(const MiptParams* p, uint32_t sample_count, RenderShape& r) {
+  const uint32_t tiles_y = (uint32_t)((p->height + 7) / 8);
+  r.tiles_x = (uint32_t)((p->width + 7) / 8);
+  r.n_slots = (uint64_t)r.tiles_x * tiles_y * 64u;
+  r.item_samples = sample_count < ITEM_SAMPLES ? sample_count : ITEM_SAMPLES;
+  r.n_sblocks = (sample_count + r.item_samples - 1) / r.item_samples;
+  r.n_items = r.n_slots * r.n_sblocks;
+  if (r.n_items >= 0xFF000000ull)
+    return fail(MIPT_E_INVALID, "mipt_render_accumulate: %llu work items in one call; render fewer samples per call",
+                (unsigned long long)r.n_items);
+  r.n_img = (size_t)p->width * p->height * 3;
+  r.sums_bytes = r.n_img * sizeof(float) * r.n_sblocks;
+  return MIPT_OK;
+}
+
+static int render_check(const MiptScene* s, const MiptCamera* cam, const MiptLight* light, const MiptParams* p,
+                        uint32_t sample_begin, uint32_t sample_count, const float* d_accum_rgb) {
   if (!s) return fail(MIPT_E_INVALID, "mipt_render_accumulate: scene is null");
   int rc = check_params("mipt_render_accumulate", cam, light, p);
   if (rc != MIPT_OK) return rc;
   if (!d_accum_rgb) return fail(MIPT_E_INVALID, "mipt_render_accumulate: accumulation buffer is null");
-  if (sample_count == 0) return MIPT_OK;
   if (sample_begin + sample_count < sample_begin)
     return fail(MIPT_E_INVALID, "mipt_render_accumulate: sample range wraps around 2^32");
-  HIP_TRY(hipSetDevice(s->device));
-  hipStream_t st = (hipStream_t)stream;
+  return MIPT_OK;
+}
 
-  // work items: ITEM_SAMPLES consecutive samples of one pixel, enumerated tile by tile (8x8
-  // pixels) and sample block by sample block; one scratch image per sample block
-  const uint32_t tiles_x = (uint32_t)((p->width + 7) / 8), tiles_y = (uint32_t)((p->height + 7) / 8);
-  const uint64_t n_slots = (uint64_t)tiles_x * tiles_y * 64u;
-  const uint32_t item_samples = sample_count < ITEM_SAMPLES ? sample_count : ITEM_SAMPLES;
-  const uint32_t n_sblocks = (sample_count + item_samples - 1) / item_samples;
-  const uint64_t n_items = n_slots * n_sblocks;
-  if (n_items >= 0xFF000000ull)
-    return fail(MIPT_E_INVALID, "mipt_render_accumulate: %llu work items in one call; render fewer samples per call",
-                (unsigned long long)n_items);
-
-  const size_t n_img = (size_t)p->width * p->height * 3;
-  const size_t need = n_img * sizeof(float) * n_sblocks;
-  if (need > s->partial_bytes) {
-    // the scratch image stack is kept with the scene and only ever grows
-    HIP_TRY(hipStreamSynchronize(st));
-    if (s->d_partial) { (void)hipFree(s->d_partial); s->d_partial = nullptr; s->partial_bytes = 0; }
-    HIP_TRY(hipMalloc(&s->d_partial, need));
-    s->partial_bytes = need;
-  }
-
+// The launches of one render call: queue head cleared, path kernel, ordered sum of the item sums
+// into the caller's image. Allocates nothing; `timed` = bracket the path kernel with the scene's events.
+static int render_launch(MiptScene* s, const MiptCamera* cam, const MiptLight* light, const MiptParams* p,
+                         uint32_t sample_begin, uint32_t sample_count, float* d_accum_rgb, hipStream_t st,
+                         const RenderShape& r, RenderScratch scr, bool timed) {
   PathArgs a;
   fill_args(a, s, cam, light, p);
   a.sample_begin = sample_begin;
   a.sample_count = sample_count;
-  a.item_samples = item_samples;
-  a.tiles_x = tiles_x;
-  a.n_slots = (uint32_t)n_slots;
-  a.n_items = (uint32_t)n_items;
-  a.queue = s->d_queue;
-  a.partial = s->d_partial;
+  a.item_samples = r.item_samples;
+  a.tiles_x = r.tiles_x;
+  a.n_slots = (uint32_t)r.n_slots;
+  a.n_items = (uint32_t)r.n_items;
+  a.queue = scr.queue;
+  a.partial = scr.sums;
   // enough resident waves to fill the chip at any occupancy; every lane loops over the queue
-  const uint64_t batches = n_items / 64u;
+  const uint64_t batches = r.n_items / 64u;
   const unsigned grid = (unsigned)(batches / 4u + 1u < PERSISTENT_BLOCKS ? batches / 4u + 1u : PERSISTENT_BLOCKS);
-  HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(scr.queue, 0, sizeof(uint32_t), st));
   const bool stats = (p->flags & MIPT_FLAG_STATS) != 0;
   if (stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, (ST_COUNT + PF_COUNT) * sizeof(unsigned long long), st));
 #ifdef MIPT_PROFILE_SECTIONS
   HIP_TRY(hipMemsetAsync(s->d_stats + ST_COUNT, 0, PF_COUNT * sizeof(unsigned long long), st));
 #endif
-  HIP_TRY(hipEventRecord(s->ev0, st));
+  if (timed) HIP_TRY(hipEventRecord(s->ev0, st));
   const size_t lds = lds_bytes(s, p, a);
   launch_paths<false>(s, a, dim3(grid), lds, st);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(s->ev1, st));
-  hipLaunchKernelGGL(k_reduce_chunks, dim3(grid_for(n_img)), dim3(BLOCK), 0, st, s->d_partial, n_sblocks, n_img,
+  if (timed) HIP_TRY(hipEventRecord(s->ev1, st));
+  hipLaunchKernelGGL(k_reduce_chunks, dim3(grid_for(r.n_img)), dim3(BLOCK), 0, st, scr.sums, r.n_sblocks, r.n_img,
                      d_accum_rgb);
   HIP_TRY(hipGetLastError());
-  s->timed = true;
+  if (timed) s->timed = true;
   s->stats_valid = stats;
   s->last_paths = (uint64_t)p->width * p->height * sample_count;
   return MIPT_OK;
+}
+
+extern "C" int mipt_render_accumulate_dev(MiptScene* s, const MiptCamera* cam, const MiptLight* light,
+                                          const MiptParams* p, uint32_t sample_begin, uint32_t sample_count,
+                                          float* d_accum_rgb, void* stream) {
+  int rc = render_check(s, cam, light, p, sample_begin, sample_count, d_accum_rgb);
+  if (rc != MIPT_OK) return rc;
+  if (sample_count == 0) return MIPT_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t st = (hipStream_t)stream;
+  RenderShape r;
+  rc = render_shape(p, sample_count, r);
+  if (rc != MIPT_OK) return rc;
+  if (r.sums_bytes > s->partial_bytes) {
+    // the scratch image stack is kept with the scene and only ever grows; a launch still reading
+    // the old one (on any stream) must have finished before it is freed
+    if (s->busy_valid) HIP_TRY(hipEventSynchronize(s->ev_busy));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (s->d_partial) { (void)hipFree(s->d_partial); s->d_partial = nullptr; s->partial_bytes = 0; }
+    HIP_TRY(hipMalloc(&s->d_partial, r.sums_bytes));
+    s->partial_bytes = r.sums_bytes;
+  }
+  rc = scratch_acquire(s, st);
+  if (rc != MIPT_OK) return rc;
+  rc = render_launch(s, cam, light, p, sample_begin, sample_count, d_accum_rgb, st, r,
+                     RenderScratch{s->d_queue, s->d_partial}, true);
+  if (rc != MIPT_OK) return rc;
+  return scratch_release(s, st);
 }
 
 extern "C" int mipt_render_accumulate(MiptScene* s, const MiptCamera* cam, const MiptLight* light,
@@ -828,6 +901,7 @@ extern "C" int mipt_trace_paths(MiptScene* s, const MiptCamera* cam, const MiptL
   a.rgb = drgb.as<float>();
   a.counts = dcnt.as<uint32_t>();
   const bool stats = (p->flags & MIPT_FLAG_STATS) != 0;
+  if (s->busy_valid) HIP_TRY(hipEventSynchronize(s->ev_busy));  // the counters are scene scratch too
   if (stats) HIP_TRY(hipMemset(s->d_stats, 0, (ST_COUNT + PF_COUNT) * sizeof(unsigned long long)));
   HIP_TRY(hipEventRecord(s->ev0, nullptr));
   const size_t lds = lds_bytes(s, p, a);
@@ -925,6 +999,7 @@ extern "C" int mipt_resolve_argb(MiptScene* s, const float* accum_rgb, int width
 
 struct MiptFrame {
   MiptScene* scene = nullptr;
+  int device = 0;  // the scene's device, kept here so that destroying the frame never reads the scene
   int width = 0, height = 0;
   uint32_t samples = 0;
   float* d_accum = nullptr;
@@ -934,7 +1009,7 @@ struct MiptFrame {
 
 extern "C" void mipt_frame_destroy(MiptFrame* f) {
   if (!f) return;
-  (void)hipSetDevice(f->scene->device);
+  (void)hipSetDevice(f->device);
   if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
   if (f->d_accum) (void)hipFree(f->d_accum);
   if (f->d_screen) (void)hipFree(f->d_screen);
@@ -959,7 +1034,7 @@ extern "C" int mipt_frame_create(MiptScene* scene, int width, int height, MiptFr
     return fail(MIPT_E_INVALID, "mipt_frame_create: image size %d x %d out of range", width, height);
   MiptFrame* f = new (std::nothrow) MiptFrame();
   if (!f) return fail(MIPT_E_NOMEM, "mipt_frame_create: host allocation failed");
-  f->scene = scene; f->width = width; f->height = height;
+  f->scene = scene; f->device = scene->device; f->width = width; f->height = height;
   const int rc = frame_create_impl(f);
   if (rc != MIPT_OK) { mipt_frame_destroy(f); return rc; }
   *out = f;

@@ -22,6 +22,7 @@
 #include <fstream>
 #include <limits>
 #include <string>
+#include <new>
 #include <vector>
 
 #include "../../include/mipt.h"
@@ -208,7 +209,7 @@ void flat_normal(MiptTriangle& t) {  // Triangle::ComputeNormal, TestModelH.h:39
 
 }  // namespace
 
-extern "C" int mipt_load_obj(const char* path, MiptTriangle* out, size_t capacity) {
+static int load_obj_impl(const char* path, MiptTriangle* out, size_t capacity) {
   if (!path) return mipt_internal_fail(MIPT_E_INVALID, "mipt_load_obj: path is null");
   const std::string p = path;
   if (p.size() < 4 || p.substr(p.size() - 4) != ".obj")  // OBJ_Loader.h:433
@@ -284,6 +285,17 @@ extern "C" int mipt_load_obj(const char* path, MiptTriangle* out, size_t capacit
   }
   if (n_out > (size_t)std::numeric_limits<int>::max()) return mipt_internal_fail(MIPT_E_INVALID, "mipt_load_obj: too many triangles");
   return (int)n_out;
+}
+
+// nothing may throw across the C ABI: allocation failures become MIPT_E_NOMEM
+extern "C" int mipt_load_obj(const char* path, MiptTriangle* out, size_t capacity) {
+  try {
+    return load_obj_impl(path, out, capacity);
+  } catch (const std::bad_alloc&) {
+    return mipt_internal_fail(MIPT_E_NOMEM, "mipt_load_obj: host allocation failed");
+  } catch (...) {
+    return mipt_internal_fail(MIPT_E_INVALID, "mipt_load_obj: unexpected exception");
+  }
 }
 
 extern "C" int mipt_normalise_triangles(MiptTriangle* tris, size_t n, float scale, const float displacement[3],

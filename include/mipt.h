@@ -12,7 +12,11 @@
  * mipt_last_error() gives a thread-local message for the last failure.
  *
  * Threading: one MiptScene handle is externally synchronised (one host thread at
- * a time); different handles may be used concurrently.
+ * a time); different handles may be used concurrently. A scene owns scratch memory
+ * on its GPU (work-queue heads, per-item radiance sums, counters) that every render
+ * and tree-batch launch uses: launches of one scene are ordered on the device in
+ * call order, whichever streams they were given (each waits for an event its
+ * predecessor recorded), so frames or streams sharing a scene never overlap there.
  *
  * Arithmetic contract: IEEE-754 binary32, every product and sum separately
  * rounded (no FMA contraction), correctly rounded division and square root,
@@ -186,7 +190,10 @@ int mipt_scene_create(const MiptTriangle* tris, size_t n_tris,
                       int device, MiptScene** out);
 /* Scenes of MIPT_BVH_MIN_TRIS triangles or more get an LBVH built on the GPU at creation
  * (the reference has none: main.cpp:19 lists "KD trees?" as a TODO and always scans linearly);
- * results are those of the linear scan. Returns 1 / 0, the count of four-wide 64-byte nodes in *n_nodes (nullable)
+ * results are those of the linear scan, with one known exception: a triangle whose box the ray
+ * never enters (or enters only beyond the nearest hit) but whose reference test is so ill
+ * conditioned for that ray that rounding noise alone makes it accept; the tree does not look at
+ * such a triangle. mipt_debug_selfcheck counts rays that differ (0 on every tested scene). Returns 1 / 0, the count of four-wide 64-byte nodes in *n_nodes (nullable)
  * and the build time in *build_ms (nullable). */
 #define MIPT_BVH_MIN_TRIS 256
 int mipt_scene_has_bvh(MiptScene* scene, uint64_t* n_nodes, double* build_ms);
@@ -259,7 +266,9 @@ int mipt_resolve_argb_dev(MiptScene* scene, const float* d_accum_rgb, int width,
  *   mipt_frame_present      Draw's tonemap loop (main.cpp:141-145) into the host screen buffer; waits
  *                           for the samples added so far
  *   mipt_frame_read_pixels  the accumulated sums, x-major W*H*3 floats (the reference's `pixels`)
- * The frame uses its scene's scratch memory: one host thread per scene, as for the other calls. */
+ * The frame uses its scene's scratch memory: one host thread per scene, as for the other calls;
+ * several frames of one scene may be driven in turn, their launches run one after the other.
+ * mipt_frame_destroy may be called after the scene was destroyed. */
 typedef struct MiptFrame MiptFrame;
 int mipt_frame_create(MiptScene* scene, int width, int height, MiptFrame** out);
 void mipt_frame_destroy(MiptFrame* frame);

@@ -405,6 +405,33 @@ def test_progressive_frame_equals_host_round_trips(api, O):
     sc.close()
 
 
+def test_two_frames_of_one_scene_interleave(api, O):
+    # two frames share their scene's scratch memory (queue head, item sums) but run on their own
+    # streams: calls that alternate between them must not overlap on the device
+    tris = O.load_test_model(2)
+    W, H = 256, 192
+    cam, light = O.default_camera(W), O.default_light(True)
+    pa = O.default_params(W, H, seed=21)
+    pb = O.default_params(W, H, seed=22, fog_sigma_t=0.3)
+    sc = api.Scene(tris)
+    fa, fb = api.Frame(sc, W, H), api.Frame(sc, W, H)
+    for _ in range(6):          # launches of a few milliseconds each, queued back to back
+        fa.add_samples(cam, light, pa, 48)
+        fb.add_samples(cam, light, pb, 16)
+    a, b = fa.read_pixels(), fb.read_pixels()
+    fa.close(); fb.close()
+    ra = rb = None
+    for k in range(6):
+        ra = sc.render_accumulate(cam, light, pa, 48 * k, 48, accum=ra)
+        rb = sc.render_accumulate(cam, light, pb, 16 * k, 16, accum=rb)
+    assert np.array_equal(bits(a), bits(ra))
+    assert np.array_equal(bits(b), bits(rb))
+    # a frame outliving its scene is destroyed without touching the scene
+    fc = api.Frame(sc, 8, 8)
+    sc.close()
+    fc.close()
+
+
 @pytest.mark.parametrize("with_sphere", [False, True])
 def test_maximum_depth_long_paths(api, O, pkg, with_sphere):
     # MIPT_MAX_DEPTH_LIMIT levels with Russian roulette nearly off: the per-lane vertex stack (and
