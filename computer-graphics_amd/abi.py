@@ -22,6 +22,7 @@ MATERIAL_NAMES = {"diffuse": MAT_DIFFUSE, "mirror": MAT_MIRROR, "glass": MAT_GLA
 
 RNG_MINSTD_PATH, RNG_COUNTER, RNG_MINSTD_GLOBAL = 0, 1, 2
 FLAG_STATS = 1
+SCENE_LINEAR_SCAN = 1  # MIPT_SCENE_LINEAR_SCAN
 MAX_DEPTH_LIMIT = 16
 
 SCENE_CORNELL, SCENE_COLOR_BLEEDING, SCENE_GLASS_CUBE, SCENE_NONE = range(4)
@@ -84,6 +85,7 @@ EXPORTS = [
     "mipt_render_accumulate_dev", "mipt_resolve_argb_dev", "mipt_get_stats", "mipt_path_key",
     "mipt_load_test_model", "mipt_default_camera", "mipt_default_light", "mipt_debug_selfcheck", "mipt_scene_has_bvh", "mipt_scene_pair_units", "mipt_scene_axis_pair_units", "mipt_load_obj", "mipt_normalise_triangles", "mipt_save_bmp", "mipt_frame_create", "mipt_frame_destroy", "mipt_frame_reset",
     "mipt_frame_add_samples", "mipt_frame_present", "mipt_frame_read_pixels", "mipt_frame_samples",
+    "mipt_scene_create_opts",
 ]
 
 
@@ -114,6 +116,7 @@ def load_library(path=None):
     lib.mipt_last_error.restype = C.c_char_p
     lib.mipt_version.restype = C.c_char_p
     lib.mipt_scene_create.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_int, P(vp)]
+    lib.mipt_scene_create_opts.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_uint32, P(vp)]
     lib.mipt_scene_destroy.argtypes = [vp]
     lib.mipt_scene_destroy.restype = None
     lib.mipt_closest_hit.argtypes = [vp, f32p, f32p, C.c_size_t, i32p, f32p, f32p]

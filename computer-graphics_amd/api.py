@@ -114,7 +114,7 @@ def path_key(seed, pixel, sample):
 class Scene:
     """Owns a MiptScene handle (device copy of the triangles / spheres)."""
 
-    def __init__(self, tris, spheres=None, device=0):
+    def __init__(self, tris, spheres=None, device=0, linear_scan=False):
         self._lib = abi.load_library()
         tris = np.ascontiguousarray(tris, dtype=abi.TRIANGLE_DTYPE)
         ns = 0 if spheres is None else len(spheres)
@@ -122,8 +122,9 @@ class Scene:
             spheres = np.ascontiguousarray(spheres, dtype=abi.SPHERE_DTYPE)
         self.n_tris, self.n_spheres, self.device = len(tris), ns, device
         h = C.c_void_p()
-        _check(self._lib.mipt_scene_create(_ptr(tris) if len(tris) else None, len(tris),
-                                           _ptr(spheres) if ns else None, ns, device, C.byref(h)))
+        _check(self._lib.mipt_scene_create_opts(_ptr(tris) if len(tris) else None, len(tris),
+                                                _ptr(spheres) if ns else None, ns, device,
+                                                abi.SCENE_LINEAR_SCAN if linear_scan else 0, C.byref(h)))
         self._h = h
 
     def close(self):
@@ -194,6 +195,7 @@ class Scene:
         _check(self._lib.mipt_debug_selfcheck(self._h, n_rays, seed, C.byref(out)))
         self.last_selfcheck_bvh = (int(out[4]), int(out[5]))  # (exhaustive re-runs, overflows)
         self.last_selfcheck_sincos = int(out[6])  # floats in [0, 2 pi] with a fused/plain sincos mismatch
+        self.last_selfcheck_grazing = int(out[7])  # tree scenes: plane-grazing rays that differ from the linear scan
         return int(out[0]), out[1] / 1024.0, int(out[2]), int(out[3])
 
     def bvh_info(self):

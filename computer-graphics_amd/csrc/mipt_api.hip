@@ -248,8 +248,10 @@ static int build_tree_scene(MiptScene* s, const MiptTriangle* tris, const std::v
     std::sort(small.begin(), small.end());
     big = by_size;
   }
-  const char* no_big = getenv("MIPT_NO_BIG_LIST");  // developer switch: every triangle in the tree
+#ifdef MIPT_DEV_SWITCHES
+  const char* no_big = getenv("MIPT_NO_BIG_LIST");  // developer build only: every triangle in the tree
   if (no_big && no_big[0] == '1') { small.insert(small.end(), big.begin(), big.end()); std::sort(small.begin(), small.end()); big.clear(); }
+#endif
   s->n_tree_tris = (int)small.size();
   if (!big.empty()) {
     HIP_TRY(hipMalloc(&s->d_big, big.size() * 4));
@@ -335,8 +337,10 @@ static bool make_pair_unit(const MiptTriangle& A, const MiptTriangle& B, ScanUni
   u.qc = (float)(1.0 / area_ratio); u.qu = (float)qu; u.qv = (float)qv;
   // A plane normal to a coordinate axis (both frame edges and the far vertex have an exactly zero
   // component there) is stored in the axis form of mipt_device.hpp: no cross products in the filter.
-  const char* no_axis = getenv("MIPT_NO_AXIS_UNITS");  // developer switch
+#ifdef MIPT_DEV_SWITCHES
+  const char* no_axis = getenv("MIPT_NO_AXIS_UNITS");  // developer build only
   if (no_axis && no_axis[0] == '1') return true;
+#endif
   for (int k = 0; k < 3; ++k) {
     if (!(f1[k] == 0.0f && f2[k] == 0.0f && q[k] - r[k] == 0.0f)) continue;
     const int i = (k + 1) % 3, j = (k + 2) % 3;
@@ -376,8 +380,11 @@ static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>
   units.assign(n_chunks * 32 + 1, ScanUnit{});
   n_pair_units = 0;
   n_axis_units = 0;
-  const char* no_pairs = getenv("MIPT_NO_PAIRS");  // developer switch: every triangle its own unit
-  const bool pairing = !(no_pairs && no_pairs[0] == '1');
+  bool pairing = true;
+#ifdef MIPT_DEV_SWITCHES
+  const char* no_pairs = getenv("MIPT_NO_PAIRS");  // developer build only: every triangle its own unit
+  pairing = !(no_pairs && no_pairs[0] == '1');
+#endif
   for (size_t c = 0; c < n_chunks; ++c) {
     const size_t lo = c * 32, hi = std::min(n, lo + 32);
     std::vector<ScanUnit> axis_pairs, pairs, singles;
@@ -419,7 +426,7 @@ static int upload_scan_units(MiptScene* s, const std::vector<ScanUnit>& units) {
 }
 
 static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
-                             size_t n_spheres, int device, MiptScene* s) {
+                             size_t n_spheres, int device, uint32_t options, MiptScene* s) {
   s->device = device;
   HIP_TRY(hipSetDevice(device));
   std::vector<TriRec> tr(n_tris + 2);  // two records of padding: the scan prefetches ahead
@@ -502,8 +509,7 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
   s->d.n_tris = (int)n_tris;
   s->d.n_spheres = (int)n_spheres;
   s->d.scale = scale;
-  const char* no_bvh = getenv("MIPT_NO_BVH");  // developer switch: always scan linearly
-  if (n_tris >= MIPT_BVH_MIN_TRIS && !(no_bvh && no_bvh[0] == '1')) return build_tree_scene(s, tris, tr, n_tris);
+  if (n_tris >= MIPT_BVH_MIN_TRIS && !(options & MIPT_SCENE_LINEAR_SCAN)) return build_tree_scene(s, tris, tr, n_tris);
   std::vector<ScanUnit> units;
   std::vector<int> all(n_tris);
   for (size_t i = 0; i < n_tris; ++i) all[i] = (int)i;
@@ -513,8 +519,15 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
 
 extern "C" int mipt_scene_create(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
                                  size_t n_spheres, int device, MiptScene** out) {
+  return mipt_scene_create_opts(tris, n_tris, spheres, n_spheres, device, 0u, out);
+}
+
+extern "C" int mipt_scene_create_opts(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
+                                      size_t n_spheres, int device, uint32_t options, MiptScene** out) {
   if (!out) return fail(MIPT_E_INVALID, "mipt_scene_create: out is null");
   *out = nullptr;
+  if (options & ~(uint32_t)MIPT_SCENE_LINEAR_SCAN)
+    return fail(MIPT_E_INVALID, "mipt_scene_create_opts: unknown option bits 0x%x", options);
   if ((n_tris && !tris) || (n_spheres && !spheres))
     return fail(MIPT_E_INVALID, "mipt_scene_create: null primitive array with non-zero count");
   if (n_tris > (size_t)1 << 24 || n_spheres > 4096)
@@ -534,7 +547,7 @@ extern "C" int mipt_scene_create(const MiptTriangle* tris, size_t n_tris, const 
   if (!s) return fail(MIPT_E_NOMEM, "mipt_scene_create: host allocation failed");
   int rc;
   try {
-    rc = scene_create_impl(tris, n_tris, spheres, n_spheres, device, s);
+    rc = scene_create_impl(tris, n_tris, spheres, n_spheres, device, options, s);
   } catch (const std::bad_alloc&) {
     rc = fail(MIPT_E_NOMEM, "mipt_scene_create: host allocation failed");
   } catch (...) {

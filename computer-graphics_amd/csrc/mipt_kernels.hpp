@@ -852,7 +852,8 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
 // Device-side self-check of the fast arithmetic against the literal one, at sizes no CPU oracle
 // can reach. out[0]: floats b (all 2^32 bit patterns) whose rcp_exact differs from IEEE 1.0f/b;
 // out[1]: largest error of the hardware estimate v_rcp_f32, in units of 2^-10 ulp, over the
-// fast-path range; out[2] / out[3]: generated rays whose FAST scan result (index, distance,
+// fast-path range; out[2] / out[3]: generated rays (camera rays, interior rays, origins on triangles
+// and on edges, rays grazing a triangle's plane) whose FAST scan result (index, distance,
 // barycentrics) differs from the literal scan, closest-hit / any-hit rule.
 
 __global__ __launch_bounds__(BLOCK) void k_selfcheck_rcp(unsigned long long* out) {
@@ -898,16 +899,39 @@ __global__ __launch_bounds__(BLOCK) void k_selfcheck_scan(DeviceScene sc, unsign
                                                           unsigned long long* out) {
   const unsigned long long gid = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
   if (gid >= n_rays) return;
-  // ray generator: four families chosen by the low bits of the ray number
+  // ray generator: five families chosen by the ray number
   uint32_t k = path_key(seed, (uint32_t)gid, (uint32_t)(gid >> 32));
   auto u01 = [&]() { k = mix32(k + 0x9E3779B9u); return (float)(k >> 8) * (1.0f / 16777216.0f); };
   V4 o, d;
-  const int family = (int)(gid & 3);
+  const int family = (int)(gid % 5ull);
   if (family == 0) {  // camera rays of a 1024^2 frame, direction not normalised
     o = {0.f, 0.f, -3.f, 1.f};
     d = {(u01() - 0.5f) * 1024.f, (u01() - 0.5f) * 1024.f, 1024.f, 0.f};
+  } else if (family == 4 && sc.n_tris > 0) {
+    // grazing rays: within ~0.01 degrees of a random triangle's plane, starting in or next to that
+    // plane, aimed past the triangle at up to two edge lengths from it -- the rays for which the
+    // reference's test is worst conditioned (its barycentrics are rounding noise), inside and
+    // outside the triangle's box
+    const TriRec T = sc.tris[(uint32_t)(u01() * (float)sc.n_tris) % (uint32_t)sc.n_tris];
+    const V3 e1 = {T.e1x, T.e1y, T.e1z}, e2 = {T.e2x, T.e2y, T.e2z};
+    V3 n = cross3(e1, e2);
+    const float ln = sqrtf(dot3(n, n)), l1 = sqrtf(dot3(e1, e1));
+    const float in = ln > 0.f ? 1.0f / ln : 0.f, i1 = l1 > 0.f ? 1.0f / l1 : 0.f;
+    n = {n.x * in, n.y * in, n.z * in};
+    const V3 a1 = {e1.x * i1, e1.y * i1, e1.z * i1};
+    const V3 a2 = cross3(n, a1);
+    const float phi = 6.2831853f * u01(), cp = cosf(phi), sp = sinf(phi);
+    const V3 w = {cp * a1.x + sp * a2.x, cp * a1.y + sp * a2.y, cp * a1.z + sp * a2.z};
+    const float a = u01() * 4.0f - 1.5f, b = u01() * 4.0f - 1.5f;
+    const float back = u01() * 3.0f * l1;
+    const uint32_t sel = (uint32_t)(u01() * 4.0f);
+    const float h = (sel == 0u ? 0.f : (u01() - 0.5f) * (sel == 1u ? 2e-6f : 2e-3f)) * l1;
+    const float tilt = sel == 3u ? 0.f : (u01() - 0.5f) * 4e-4f;
+    o = {(T.v0x + a * e1.x) + b * e2.x - back * w.x + h * n.x, (T.v0y + a * e1.y) + b * e2.y - back * w.y + h * n.y,
+         (T.v0z + a * e1.z) + b * e2.z - back * w.z + h * n.z, 1.f};
+    d = normalize4({w.x + tilt * n.x, w.y + tilt * n.y, w.z + tilt * n.z, u01() < 0.5f ? 0.f : 1.0f});
   } else {
-    if (family == 1 || sc.n_tris == 0) {  // incoherent rays from inside the box
+    if (family == 1 || family == 4 || sc.n_tris == 0) {  // incoherent rays from inside the box
       o = {u01() * 1.9f - 0.95f, u01() * 1.9f - 0.95f, u01() * 1.9f - 0.95f, 1.f};
     } else {  // origin exactly on a triangle (family 2) or exactly on one of its edges (family 3)
       const TriRec T = sc.tris[(uint32_t)(u01() * (float)sc.n_tris) % (uint32_t)sc.n_tris];
@@ -938,7 +962,12 @@ __global__ __launch_bounds__(BLOCK) void k_selfcheck_scan(DeviceScene sc, unsign
     };
     // any-hit through the tree reports only whether a triangle accepts, not which
     const bool g_ok = (mode && sc.bvh) ? (g.idx == e.idx) : same(g, e);
-    if (!same(f, e) || !g_ok) atomicAdd(out + 2 + mode, 1ull);
+    // The tree on grazing rays is counted apart (out[7]): a triangle whose box such a ray never
+    // enters can still be accepted by the reference's test out of pure rounding noise, and the walk
+    // cannot know. The scans without a tree must be exact for every family.
+    const bool apart = BVH && family == 4;
+    if (!same(f, e) || (!g_ok && !apart)) atomicAdd(out + 2 + mode, 1ull);
+    if (!g_ok && apart) atomicAdd(out + 7, 1ull);
   }
 }
 

@@ -196,6 +196,13 @@ int mipt_scene_create(const MiptTriangle* tris, size_t n_tris,
  * such a triangle. mipt_debug_selfcheck counts rays that differ (0 on every tested scene). Returns 1 / 0, the count of four-wide 64-byte nodes in *n_nodes (nullable)
  * and the build time in *build_ms (nullable). */
 #define MIPT_BVH_MIN_TRIS 256
+/* mipt_scene_create with options. MIPT_SCENE_LINEAR_SCAN: never build the tree -- every query scans
+ * all triangles in index order like intersections.cpp:11-37 does, whatever the scene's size (slow
+ * beyond a few thousand triangles; it is the on-device cross-check of the tree). */
+enum { MIPT_SCENE_LINEAR_SCAN = 1u };
+int mipt_scene_create_opts(const MiptTriangle* tris, size_t n_tris,
+                           const MiptSphere* spheres, size_t n_spheres,
+                           int device, uint32_t options, MiptScene** out);
 int mipt_scene_has_bvh(MiptScene* scene, uint64_t* n_nodes, double* build_ms);
 /* Linear-scan scenes: how many pairs of consecutive coplanar triangles sharing an edge (the two
  * halves of a wall or box face, TestModelH.h:87-160) the candidate filter treats as one unit.
@@ -287,12 +294,15 @@ int mipt_get_stats(MiptScene* scene, MiptStats* out);
 /* Self-check with no counterpart in the reference: runs on the GPU (1) the library's fast
  * correctly-rounded reciprocal against IEEE 1.0f/b for all 2^32 floats and (2) its fast triangle
  * scan against the literal reference arithmetic on n_rays generated rays (camera rays, incoherent
- * interior rays, origins on triangle surfaces and edges), closest-hit and any-hit rule.
+ * interior rays, origins on triangle surfaces and edges, rays within 0.01 degrees of a triangle's
+ * plane), closest-hit and any-hit rule.
  * For a scene with an LBVH, (2) compares the tree traversal with the literal linear scan.
  * out[0] = reciprocal mismatches, out[1] = worst error of the hardware reciprocal estimate in
  * 2^-10 ulp, out[2] / out[3] = rays whose closest-hit / any-hit result differs, out[4] = rays
  * re-run through the exhaustive tree traversal, out[5] = traversal overflows, out[6] = floats in
- * [0, 2 pi] whose fused-arithmetic sine / cosine differs from the plain evaluation, out[7] = 0.
+ * [0, 2 pi] whose fused-arithmetic sine / cosine differs from the plain evaluation, out[7] = tree
+ * scenes only: plane-grazing rays (a fifth of n_rays) whose tree result differs from the linear scan,
+ * counted apart from out[2] / out[3] -- the known exception described at MIPT_BVH_MIN_TRIS.
  * All of out[0], out[2], out[3], out[5], out[6] must be 0. */
 int mipt_debug_selfcheck(MiptScene* scene, uint64_t n_rays, uint32_t seed, uint64_t out[8]);
 

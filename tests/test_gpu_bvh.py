@@ -53,10 +53,17 @@ def test_tree_equals_literal_scan_on_device(api, O, dtype, name):
     rcp_bad, _, closest_bad, any_bad = sc.selfcheck(n_rays, seed=5)
     redo, overflow = sc.last_selfcheck_bvh
     sc.close()
+    grazing = sc.last_selfcheck_grazing
     print(f"{name}: {len(tris)} triangles, build {build_ms:.2f} ms, {n_rays} rays: "
-          f"closest_bad={closest_bad} any_bad={any_bad} redo={redo} overflow={overflow}")
+          f"closest_bad={closest_bad} any_bad={any_bad} redo={redo} overflow={overflow} grazing_bad={grazing}")
     assert rcp_bad == 0 and overflow == 0
     assert closest_bad == 0 and any_bad == 0, (closest_bad, any_bad)
+    # a fifth of the rays lie within 0.01 degrees of a random triangle's plane and start in or next to
+    # it: the reference's test of such a triangle is rounding noise and can accept a ray that never
+    # enters the triangle's box. The one documented difference between tree and linear scan; it
+    # must stay at a few per million of THESE rays (rays a path tracer generates do not graze)
+    assert grazing * 1000000 <= 20 * (n_rays // 5), grazing
+    sc.close()
     assert redo < n_rays // 100  # the exhaustive traversal is the exception
 
 
@@ -257,3 +264,165 @@ def test_tree_batches_of_any_size(api, O, dtype):
         occ = sc.any_hit(so[:n], sd[:n], sr[:n])
         assert np.array_equal(occ, O.any_hit(tris, so[:n], sd[:n], sr[:n])), n
     sc.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# The kernels that ship for tree scenes -- k_bvh_batch (queue heads, bursts, LDS stack) behind
+# closest_hit / any_hit and k_paths<..., SCENE_BVH> behind render_accumulate -- on the two large
+# configurations, against the linear scan of the same triangles on the device
+# (Scene(..., linear_scan=True): every triangle in index order, intersections.cpp:11-37) and
+# against the CPU oracle.
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _batch(sc, o, d, r=None):
+    import torch
+    n = o.shape[0]
+    idx = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    t = torch.zeros(n, dtype=torch.float32, device="cuda")
+    pos = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    sc.closest_hit_dev(o, d, idx, t, pos)
+    occ = None
+    if r is not None:
+        occ = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        sc.any_hit_dev(o, d, r, occ)
+    torch.cuda.synchronize()
+    return idx, t, pos, occ
+
+
+def _same_hits(a, b):
+    import torch
+    ia, ta, pa, oa = a
+    ib, tb, pb, ob = b
+    hit = ib >= 0
+    ok = torch.equal(ia, ib) and torch.equal(ta[hit].view(torch.int32), tb[hit].view(torch.int32)) and \
+        torch.equal(pa[hit].view(torch.int32), pb[hit].view(torch.int32))
+    if oa is not None:
+        ok = ok and torch.equal(oa, ob)
+    return ok
+
+
+@pytest.mark.parametrize("name", ["config4", "config5"])
+def test_shipped_batch_kernels_equal_linear_scan_on_big_configs(api, O, dtype, name):
+    import torch
+    tris = scenes(O, dtype)[name]()
+    tree = api.Scene(tris)
+    lin = api.Scene(tris, linear_scan=True)
+    assert tree.bvh_info()[0] and not lin.bvh_info()[0]
+    n = 1 << 18
+    fams = {"primary": raygen.primary_rays(n), "interior": raygen.interior_rays(n, seed=12),
+            "surface": raygen.surface_rays(tris, n, seed=13)}
+    so, sd, sr = raygen.shadow_rays(tris, n, seed=14)
+    for kind, (o, d) in fams.items():
+        o, d = _dev(o), _dev(d)
+        a = _batch(tree, o, d)
+        b = _batch(lin, o, d)
+        assert _same_hits(a, b), (name, kind, int((a[0] != b[0]).sum()))
+        assert (b[0] >= 0).float().mean() > 0.05, kind
+    o, d, r = _dev(so), _dev(sd), _dev(sr)
+    a = _batch(tree, o, d, r)
+    b = _batch(lin, o, d, r)
+    assert torch.equal(a[3], b[3]) and 0 < int(b[3].sum()) < n
+    # ~1000 rays of each kind against the CPU oracle
+    m = 1024 if len(tris) < 500000 else 256
+    for kind, (o, d) in fams.items():
+        idx, t, pos = tree.closest_hit(o[:m], d[:m])
+        oidx, ot, opos = O.closest_hit(tris, None, o[:m], d[:m])
+        assert np.array_equal(idx, oidx), (name, kind)
+        hit = oidx >= 0
+        assert np.array_equal(bits(t[hit]), bits(ot[hit])) and np.array_equal(bits(pos[hit]), bits(opos[hit]))
+    assert np.array_equal(tree.any_hit(so[:m], sd[:m], sr[:m]), O.any_hit(tris, so[:m], sd[:m], sr[:m]))
+    if name == "config5":
+        # the full 3840 x 2160 batch of the configuration: the result of a ray does not depend on the
+        # batch it travels in (queue heads, reservation, which lane walks it), and a strided 2^18 of
+        # them equal the linear scan
+        n_all = 3840 * 2160
+        o, d = raygen.interior_rays(n_all, seed=42)
+        o, d = _dev(o), _dev(d)
+        full = _batch(tree, o, d)
+        again = _batch(tree, o, d)
+        assert _same_hits(full, again)
+        pick = torch.arange(0, n_all, n_all // (1 << 18), device="cuda")[: 1 << 18]
+        po, pd = o[pick].contiguous(), d[pick].contiguous()
+        sub_tree = _batch(tree, po, pd)
+        sub_lin = _batch(lin, po, pd)
+        assert _same_hits(sub_tree, sub_lin)
+        assert _same_hits((full[0][pick], full[1][pick], full[2][pick], None), sub_lin)
+        assert (full[0] >= 0).float().mean() > 0.5
+    tree.close(); lin.close()
+
+
+def test_shipped_path_kernel_on_config4(api, O, dtype, pkg):
+    # whole paths through the 102 410-triangle scene at the configuration's 1024^2: the shipped kernel
+    # (flags = 0) and the counting kernel give the same image bit for bit; against the linear scan of
+    # the same scene: equal ray and bounce counters, >= 99 % of the pixels bit-equal (the rest: the one
+    # power function whose last bit differs between paths that hit the same glass twice), no overflow
+    import torch
+    tris = scenes(O, dtype)["config4"]()
+    W = H = 1024
+    cam, light = api.default_camera(W), api.default_light(True)
+    tree = api.Scene(tris)
+    lin = api.Scene(tris, linear_scan=True)
+    for rng_mode, fog in ((pkg.abi.RNG_COUNTER, 0.0), (pkg.abi.RNG_MINSTD_PATH, 0.1)):
+        p0 = api.default_params(W, H, seed=3, rng_mode=rng_mode, fog_sigma_t=fog)
+        p1 = api.default_params(W, H, seed=3, rng_mode=rng_mode, fog_sigma_t=fog, flags=pkg.abi.FLAG_STATS)
+        plain = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+        counted = torch.zeros_like(plain)
+        tree.render_accumulate_dev(cam, light, p0, 0, 16, plain)
+        tree.render_accumulate_dev(cam, light, p1, 0, 16, counted)
+        torch.cuda.synchronize()
+        st = tree.stats()
+        assert torch.equal(plain.view(torch.int32), counted.view(torch.int32)), (rng_mode, fog)
+        assert st.bvh_overflow == 0 and st.paths == W * H * 16 and st.glass_bounces > 100000
+        assert st.bvh_redo < st.closest_rays // 1000
+    # the linear scan of 102 410 triangles is slow: 2 of the 16 samples
+    p1 = api.default_params(W, H, seed=3, rng_mode=pkg.abi.RNG_COUNTER, flags=pkg.abi.FLAG_STATS)
+    a = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    b = torch.zeros_like(a)
+    tree.render_accumulate_dev(cam, light, p1, 0, 2, a)
+    torch.cuda.synchronize()
+    st = tree.stats()
+    lin.render_accumulate_dev(cam, light, p1, 0, 2, b)
+    torch.cuda.synchronize()
+    sl = lin.stats()
+    for k in ("paths", "closest_rays", "shadow_rays", "diffuse_bounces", "mirror_bounces", "glass_bounces"):
+        assert getattr(st, k) == getattr(sl, k), (k, getattr(st, k), getattr(sl, k))
+    same = (a.view(torch.int32).view(-1, 3) == b.view(torch.int32).view(-1, 3)).all(dim=1).float().mean().item()
+    assert same >= 0.99, same
+    tree.close(); lin.close()
+
+
+@pytest.mark.parametrize("name", ["mesh9k", "glasswolf", "soup300"])
+def test_shipped_path_kernels_equal_counting_kernels(api, O, dtype, pkg, name):
+    # flags = 0 (the kernels that ship: early end at unlit terminal vertices, other register and LDS
+    # budgets) against FLAG_STATS, bit for bit, on tree scenes and on a linear-scan scene too large
+    # for the LDS tables (SCENE_LINEAR, 65..255 primitives); both RNG modes, fog, a sphere; and the
+    # shipped kernel against the CPU oracle
+    if name == "glasswolf":
+        tris = glasswolf_scene(pkg)
+    elif name == "soup300":
+        tris = np.concatenate([bigscenes.room(O), bigscenes.soup(dtype, 190, seed=9, size=0.2)])  # 200 triangles
+    else:
+        tris = scenes(O, dtype)[name]
+    sph = api.make_sphere(0.3, [-0.45, 0.7, -0.55, 1], [1, 0, 0])
+    W, H, spp = 64, 48, 8
+    cam, light = api.default_camera(W), api.default_light(True)
+    for spheres in (None, sph):
+        sc = api.Scene(tris, spheres)
+        assert sc.bvh_info()[0] == (len(tris) >= 256)
+        for rng_mode in (pkg.abi.RNG_MINSTD_PATH, pkg.abi.RNG_COUNTER):
+            for fog in (0.0, 0.3):
+                kw = dict(seed=7, rng_mode=rng_mode, fog_sigma_t=fog)
+                plain = sc.render_accumulate(cam, light, api.default_params(W, H, **kw), 0, spp)
+                counted = sc.render_accumulate(cam, light, api.default_params(W, H, flags=pkg.abi.FLAG_STATS, **kw), 0, spp)
+                assert np.array_equal(bits(plain), bits(counted)), (name, rng_mode, fog)
+                assert plain.sum() > 0
+        if spheres is None:
+            p = api.default_params(W, H, seed=7)
+            img = sc.render_accumulate(cam, light, p, 0, 4)
+            ref, _ = O.render_accumulate(tris, None, cam, light, p, 0, 4)
+            assert (bits(img) == bits(ref)).all(axis=2).mean() > 0.99
+        sc.close()
