@@ -24,6 +24,7 @@ RNG_MINSTD_PATH, RNG_COUNTER, RNG_MINSTD_GLOBAL = 0, 1, 2
 FLAG_STATS = 1
 SCENE_LINEAR_SCAN = 1  # MIPT_SCENE_LINEAR_SCAN
 MAX_DEPTH_LIMIT = 16
+NOALLOC_MAX_BYTES = 32 << 20  # MIPT_NOALLOC_MAX_BYTES
 
 SCENE_CORNELL, SCENE_COLOR_BLEEDING, SCENE_GLASS_CUBE, SCENE_NONE = range(4)
 
@@ -85,7 +86,7 @@ EXPORTS = [
     "mipt_render_accumulate_dev", "mipt_resolve_argb_dev", "mipt_get_stats", "mipt_path_key",
     "mipt_load_test_model", "mipt_default_camera", "mipt_default_light", "mipt_debug_selfcheck", "mipt_scene_has_bvh", "mipt_scene_pair_units", "mipt_scene_axis_pair_units", "mipt_load_obj", "mipt_normalise_triangles", "mipt_save_bmp", "mipt_frame_create", "mipt_frame_destroy", "mipt_frame_reset",
     "mipt_frame_add_samples", "mipt_frame_present", "mipt_frame_read_pixels", "mipt_frame_samples",
-    "mipt_scene_create_opts",
+    "mipt_render_accumulate_noalloc_dev", "mipt_scene_create_opts",
 ]
 
 
@@ -131,6 +132,7 @@ def load_library(path=None):
     lib.mipt_render_accumulate_dev.argtypes = [vp, P(MiptCamera), P(MiptLight), P(MiptParams),
                                                C.c_uint32, C.c_uint32, f32p, vp]
     lib.mipt_resolve_argb_dev.argtypes = [vp, f32p, C.c_int, C.c_int, C.c_uint32, u32p, vp]
+    lib.mipt_render_accumulate_noalloc_dev.argtypes = lib.mipt_render_accumulate_dev.argtypes
     lib.mipt_get_stats.argtypes = [vp, P(MiptStats)]
     lib.mipt_path_key.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     lib.mipt_path_key.restype = C.c_uint32

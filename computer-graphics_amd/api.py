@@ -243,6 +243,15 @@ class Scene:
                                                     C.byref(params), sample_begin, sample_count,
                                                     accum.data_ptr(), self._stream()))
 
+    def render_accumulate_noalloc_dev(self, cam, light, params, sample_begin, sample_count, accum):
+        """render_accumulate_dev through the entry point that allocates nothing (fixed scratch in the
+        library, at most abi.NOALLOC_MAX_BYTES of item sums per call)."""
+        if accum.numel() != params.width * params.height * 3 or not accum.is_contiguous():
+            raise ValueError("accum must be a contiguous float32 tensor of W*H*3 elements")
+        _check(self._lib.mipt_render_accumulate_noalloc_dev(self._h, C.byref(cam), C.byref(light),
+                                                            C.byref(params), sample_begin, sample_count,
+                                                            accum.data_ptr(), self._stream()))
+
     def resolve_argb_dev(self, accum, width, height, n_samples, screen):
         _check(self._lib.mipt_resolve_argb_dev(self._h, accum.data_ptr(), width, height, n_samples,
                                                screen.data_ptr(), self._stream()))

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <iterator>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -44,6 +45,33 @@ extern "C" const char* mipt_last_error(void) { return g_err; }
 // for the host-only translation units of the library
 extern "C" int mipt_internal_fail(int code, const char* msg) { return fail(code, "%s", msg); }
 extern "C" const char* mipt_version(void) { return "mipt 0.1 gfx950 hip"; }
+
+// ---------------------------------------------------------------------------------------
+// Scratch of the entry point that allocates nothing (mipt_render_accumulate_noalloc_dev): the path
+// kernel's work-queue head (first 256 bytes) and its per-item radiance sums, in a file-scope device
+// array. Every GPU the library runs on holds its own copy at its own address until the process
+// ends. In host code the array's NAME is only a stand-in for the symbol -- never a device address:
+// noalloc_setup() asks HIP for the address once per device (with that device current) and host
+// code uses that pointer from then on.
+constexpr size_t NOALLOC_QUEUE_BYTES = 256;
+constexpr size_t NOALLOC_SUMS_BYTES = (size_t)MIPT_NOALLOC_MAX_BYTES;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_QUEUE_BYTES + NOALLOC_SUMS_BYTES];
+
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static std::mutex g_noalloc_mutex;
+static unsigned char* g_noalloc_ptr[NOALLOC_MAX_DEVICES] = {};
+
+// Called with `device` current (mipt_scene_create): the address of this device's copy of `scratch`.
+static int noalloc_setup(int device) {
+  if (device < 0 || device >= NOALLOC_MAX_DEVICES) return MIPT_OK;  // such a device simply has no no-alloc path
+  std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+  if (g_noalloc_ptr[device]) return MIPT_OK;
+  void* ptr = nullptr;
+  HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+  if (!ptr) return fail(MIPT_E_HIP, "hipGetSymbolAddress(scratch) returned a null address on device %d", device);
+  g_noalloc_ptr[device] = static_cast<unsigned char*>(ptr);
+  return MIPT_OK;
+}
 
 // ---------------------------------------------------------------------------------------
 // scene
@@ -503,6 +531,10 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
   HIP_TRY(hipEventCreateWithFlags(&s->ev_busy, hipEventDisableTiming));
+  {
+    const int rc = noalloc_setup(device);
+    if (rc != MIPT_OK) return rc;
+  }
   s->d.tris = s->d_tris;
   s->d.shade = s->d_shade;
   s->d.spheres = s->d_spheres;
@@ -867,6 +899,32 @@ extern "C" int mipt_render_accumulate_dev(MiptScene* s, const MiptCamera* cam, c
                      RenderScratch{s->d_queue, s->d_partial}, true);
   if (rc != MIPT_OK) return rc;
   return scratch_release(s, st);
+}
+
+// The same call for callers that must not allocate (code under HIP graph capture, tight serving
+// loops): queue head and item sums live in the file-scope array `scratch` of this device, whose
+// address noalloc_setup() fetched at scene creation. No hipMalloc / hipFree, no events.
+extern "C" int mipt_render_accumulate_noalloc_dev(MiptScene* s, const MiptCamera* cam, const MiptLight* light,
+                                                  const MiptParams* p, uint32_t sample_begin,
+                                                  uint32_t sample_count, float* d_accum_rgb, void* stream) {
+  int rc = render_check(s, cam, light, p, sample_begin, sample_count, d_accum_rgb);
+  if (rc != MIPT_OK) return rc;
+  if (sample_count == 0) return MIPT_OK;
+  RenderShape r;
+  rc = render_shape(p, sample_count, r);
+  if (rc != MIPT_OK) return rc;
+  if (r.sums_bytes > NOALLOC_SUMS_BYTES)
+    return fail(MIPT_E_INVALID,
+                "mipt_render_accumulate_noalloc_dev: %d x %d pixels x %u samples need %zu bytes of item sums, the "
+                "fixed scratch holds %zu (MIPT_NOALLOC_MAX_BYTES); render fewer samples per call",
+                p->width, p->height, sample_count, r.sums_bytes, NOALLOC_SUMS_BYTES);
+  unsigned char* base = (s->device >= 0 && s->device < NOALLOC_MAX_DEVICES) ? g_noalloc_ptr[s->device] : nullptr;
+  if (!base) return fail(MIPT_E_UNSUPPORTED, "mipt_render_accumulate_noalloc_dev: no scratch address for device %d", s->device);
+  HIP_TRY(hipSetDevice(s->device));
+  return render_launch(s, cam, light, p, sample_begin, sample_count, d_accum_rgb, (hipStream_t)stream, r,
+                       RenderScratch{reinterpret_cast<uint32_t*>(base),
+                                     reinterpret_cast<float*>(base + NOALLOC_QUEUE_BYTES)},
+                       false);
 }
 
 extern "C" int mipt_render_accumulate(MiptScene* s, const MiptCamera* cam, const MiptLight* light,

@@ -263,6 +263,23 @@ int mipt_render_accumulate_dev(MiptScene* scene, const MiptCamera* cam, const Mi
 int mipt_resolve_argb_dev(MiptScene* scene, const float* d_accum_rgb, int width, int height,
                           uint32_t n_samples, uint32_t* d_screen_buffer, void* stream);
 
+/* mipt_render_accumulate_dev for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc). It has no counterpart in the
+ * reference. Same arguments, same results bit for bit; the path kernel's work-queue head and
+ * per-item radiance sums live in a fixed array inside the library's code object instead of the
+ * scene's growable scratch, and the call makes no hipMalloc / hipFree / event call: one memset, the
+ * path kernel and the ordered sum, all on `stream`.
+ *   Limit: width * height * 12 bytes * ceil(sample_count / 16) <= MIPT_NOALLOC_MAX_BYTES
+ *   (1024 x 1024 at up to 32 samples per call, 512 x 512 at up to 128); larger calls return
+ *   MIPT_E_INVALID -- split the sample range over several calls, ranges compose exactly.
+ *   The array is shared by every scene and stream on a GPU (each GPU has its own copy, resident
+ *   until the process ends): two such calls that overlap on one GPU race; issue them on one stream
+ *   or order them yourself. mipt_get_stats' kernel_ms is not updated by this call. */
+#define MIPT_NOALLOC_MAX_BYTES (32u << 20)
+int mipt_render_accumulate_noalloc_dev(MiptScene* scene, const MiptCamera* cam, const MiptLight* light,
+                                       const MiptParams* params, uint32_t sample_begin,
+                                       uint32_t sample_count, float* d_accum_rgb, void* stream);
+
 /* Progressive rendering with the image resident on the device: `vec3** pixels` + `samplesSeenSoFar`
  * (main.cpp:50-56) as one object, so that a frame of the interactive loop (main.cpp:98-103) moves
  * only the ARGB screen over PCIe.
