@@ -80,3 +80,40 @@ def test_rank_sample_range_partitions(pkg):
                 pos += c
     with pytest.raises(ValueError):
         parallel.rank_sample_range(0, 4, 2, 2)
+
+
+def test_bench_launcher_starts_the_ranks(tmp_path, O, pkg, capfd):
+    # `python bench.py --gpus N` without torchrun: bench.spawn_ranks starts N rank processes with
+    # the rendezvous environment set. Here with a CPU stand-in for the rank (gloo, oracle renderer)
+    import json
+    import bench
+    out = str(tmp_path / "total.npy")
+    stub = os.path.join(ROOT, "tests", "bench_rank_stub.py")
+    steps, warmup, spp = 2, 1, 7
+    rc = bench.spawn_ranks(2, [str(steps), str(warmup), str(spp), out], script=stub)
+    assert rc == 0
+    lines = [l for l in capfd.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == steps and line["value"] > 0
+    # rank 0's image holds the samples of all (warmup + steps) steps, from both ranks
+    got = np.load(out).reshape(20, 16, 3)
+    tris = O.load_test_model(2)
+    cam, light = O.default_camera(20), O.default_light(True)
+    params = O.default_params(20, 16, rng_mode=pkg.abi.RNG_COUNTER, seed=9)
+    want, _ = O.render_accumulate(tris, None, cam, light, params, 0, spp * (steps + warmup))
+    assert want.sum() > 0 and np.allclose(got, want, rtol=1e-5, atol=1e-7)
+    # a rank that dies takes the job down with its exit code instead of hanging the others
+    assert bench.spawn_ranks(2, [str(steps), str(warmup), str(spp), out, "fail-on-rank-1"], script=stub) == 7
+
+
+def test_bench_becomes_the_launcher_for_gpus_above_one(monkeypatch, pkg):
+    # the driver's `python bench.py --gpus 8`: no WORLD_SIZE in the environment -> 8 ranks are started
+    import bench
+    seen = {}
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench, "spawn_ranks", lambda n, argv, **kw: seen.update(n=n, argv=list(argv)) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and seen["n"] == 8 and seen["argv"] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
