@@ -61,7 +61,8 @@ class MiptStats(C.Structure):
                 ("tri_tests", C.c_uint64), ("gate_passes", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("fog_events", C.c_uint64), ("diffuse_bounces", C.c_uint64),
                 ("mirror_bounces", C.c_uint64), ("glass_bounces", C.c_uint64), ("bvh_redo", C.c_uint64),
-                ("bvh_overflow", C.c_uint64), ("bvh_nodes", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("bvh_overflow", C.c_uint64), ("bvh_nodes", C.c_uint64), ("kernel_ms", C.c_double),
+                ("specular_bounces", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -765,10 +765,16 @@ static int scene_kind(const MiptScene* s) {
 
 // dynamic LDS of the path kernel: the per-lane vertex stack, then (small scenes) the record tables
 static size_t lds_bytes(const MiptScene* s, const MiptParams* p, PathArgs& a) {
-  size_t per_level = (size_t)BLOCK * 4 * (s->d.n_spheres > 0 ? 5 : 1);
-  size_t bytes = per_level * (size_t)p->max_depth;
+  // the vertex stack(s) of tags, then the sphere normals beside them, then the record tables
+  const int kind = scene_kind(s);
+  const size_t tag_size = kind == SCENE_LINEAR_LDS ? 1 : kind == SCENE_LINEAR ? 2 : 4;
+  const size_t n_stacks = paths_deferred(kind, s->d.n_spheres) ? 2 : 1;
+  size_t bytes = n_stacks * (size_t)p->max_depth * BLOCK * tag_size;
+  bytes = (bytes + 63) & ~(size_t)63;
+  a.lds_sph_off = (uint32_t)(bytes / 4);
+  if (s->d.n_spheres > 0) bytes += (size_t)p->max_depth * BLOCK * 16;
   a.lds_table_off = (uint32_t)(bytes / 4);
-  if (scene_kind(s) == SCENE_LINEAR_LDS)
+  if (kind == SCENE_LINEAR_LDS)
     bytes += (size_t)s->d.n_tris * sizeof(TriRec) + (size_t)(s->d.n_tris + s->d.n_spheres) * sizeof(ShadeRec);
   return bytes;
 }
@@ -1011,6 +1017,10 @@ extern "C" int mipt_get_stats(MiptScene* s, MiptStats* out) {
     fprintf(stderr, " (total %.3g ticks); candidates per query %.2f, phase-2 rounds per wave query %.2f\n", tot,
             (double)pf[PF_N_CANDS] / (double)(pf[PF_N_QUERIES] ? pf[PF_N_QUERIES] : 1),
             64.0 * (double)pf[PF_N_ROUNDS] / (double)(pf[PF_N_QUERIES] ? pf[PF_N_QUERIES] : 1));
+    fprintf(stderr, "[mipt sections] completion: %.3f flushes per iteration, %.2f jobs per flush, %.2f vertices per job\n",
+            (double)pf[PF_N_FLUSH] / (double)(pf[PF_N_ITERS] ? pf[PF_N_ITERS] : 1),
+            (double)pf[PF_N_JOBS] / (double)(pf[PF_N_FLUSH] ? pf[PF_N_FLUSH] : 1),
+            (double)pf[PF_N_JOB_LEVELS] / (double)(pf[PF_N_JOBS] ? pf[PF_N_JOBS] : 1));
     fprintf(stderr, "[mipt sections] queries with >= 3 / 4 / 6 candidates: %.2f %% / %.2f %% / %.3f %%\n",
             100.0 * (double)pf[PF_N_GE3] / (double)(pf[PF_N_QUERIES] ? pf[PF_N_QUERIES] : 1),
             100.0 * (double)pf[PF_N_GE4] / (double)(pf[PF_N_QUERIES] ? pf[PF_N_QUERIES] : 1),
@@ -1026,6 +1036,7 @@ extern "C" int mipt_get_stats(MiptScene* s, MiptStats* out) {
     out->sphere_tests = h[ST_SPHERE]; out->fog_events = h[ST_FOG];
     out->diffuse_bounces = h[ST_DIFFUSE]; out->mirror_bounces = h[ST_MIRROR]; out->glass_bounces = h[ST_GLASS];
     out->bvh_redo = h[ST_BVH_REDO]; out->bvh_overflow = h[ST_BVH_OVERFLOW]; out->bvh_nodes = h[ST_BVH_NODES];
+    out->specular_bounces = h[ST_SPECULAR];
   }
   return MIPT_OK;
 }

@@ -105,7 +105,7 @@ struct DeviceScene {
 
 enum StatSlot {
   ST_PATHS = 0, ST_CLOSEST, ST_SHADOW, ST_TESTS, ST_GATE, ST_SPHERE, ST_FOG, ST_DIFFUSE, ST_MIRROR,
-  ST_GLASS, ST_BVH_REDO, ST_BVH_OVERFLOW, ST_BVH_NODES, ST_COUNT
+  ST_GLASS, ST_BVH_REDO, ST_BVH_OVERFLOW, ST_BVH_NODES, ST_SPECULAR, ST_COUNT
 };
 
 #define MIPT_CONST __attribute__((address_space(4)))

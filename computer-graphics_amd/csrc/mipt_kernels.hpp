@@ -22,8 +22,11 @@ namespace mipt {
 constexpr uint32_t ITEM_SAMPLES = MIPT_ITEM_SAMPLES;
 constexpr uint32_t PERSISTENT_BLOCKS = 2048;
 
+// Tags of the per-lane vertex stack: a primitive index (diffuse vertex), or one of two marks at the
+// top of the tag type's range.
 constexpr uint32_t TAG_GLASS = 0xFFFFFFFEu;
 constexpr uint32_t TAG_FOG = 0xFFFFFFFDu;
+constexpr uint32_t TERMINAL_IN_MEDIUM = 0xFFFFFFFFu;  // terminal record: the path ended on a fog event
 
 struct PathArgs {
   DeviceScene sc;
@@ -52,6 +55,7 @@ struct PathArgs {
   uint32_t n_paths;
   float* rgb;
   uint32_t* counts;
+  uint32_t lds_sph_off;    // dword offset of the sphere normals beside the vertex stack in dynamic LDS
   uint32_t lds_table_off;  // SCENE_LINEAR_LDS: dword offset of the record tables in dynamic LDS
   unsigned long long* stats;  // ST_COUNT device counters, STATS builds only
 };
@@ -63,7 +67,8 @@ struct PathArgs {
 // the previous mark to the section's LDS counter; mipt_get_stats prints the totals.
 enum ProfSection {
   PF_QUEUE = 0, PF_RAYGEN, PF_PHASE1, PF_PHASE2, PF_HIT, PF_TERMINAL, PF_SCATTER, PF_DIFFUSE, PF_MIRROR,
-  PF_GLASS, PF_RENORM, PF_UNWIND, PF_N_QUERIES, PF_N_CANDS, PF_N_ROUNDS, PF_N_GE3, PF_N_GE4, PF_N_GE6, PF_COUNT
+  PF_GLASS, PF_RENORM, PF_UNWIND, PF_N_QUERIES, PF_N_CANDS, PF_N_ROUNDS, PF_N_GE3, PF_N_GE4, PF_N_GE6,
+  PF_N_ITERS, PF_N_FLUSH, PF_N_JOBS, PF_N_JOB_LEVELS, PF_COUNT
 };
 #ifdef MIPT_PROFILE_SECTIONS
 struct Prof {
@@ -106,6 +111,14 @@ enum ScanMode { SCAN_LITERAL = 0, SCAN_FAST = 1, SCAN_TWO_PHASE = 2 };
 // memory, LBVH.
 enum SceneKind { SCENE_LINEAR_LDS = 0, SCENE_LINEAR = 1, SCENE_BVH = 2 };
 constexpr int LDS_TABLE_MAX = 64;
+// The vertex stack holds primitive indices: a byte each for the scenes whose tables fit LDS (at most
+// 64 primitives), 16 bits for the other linear scenes (< 256 triangles + at most 4096 spheres).
+template <int KIND> struct TagType { typedef uint32_t T; };
+template <> struct TagType<SCENE_LINEAR_LDS> { typedef uint8_t T; };
+template <> struct TagType<SCENE_LINEAR> { typedef uint16_t T; };
+// Linear-scan scenes without spheres finish their lit paths in batches (see k_paths): two vertex
+// stacks, two terminal records and two radiance sums per lane.
+__host__ __device__ inline bool paths_deferred(int kind, int n_spheres) { return kind != SCENE_BVH && n_spheres == 0; }
 
 #ifndef MIPT_SCAN_MODE
 #define MIPT_SCAN_MODE 2
@@ -128,6 +141,9 @@ __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d
   if (!(Dm >= 9.094947e-13f && Dm <= 1.0995116e12f && Om <= 1.0995116e12f)) Dm = __builtin_inff();
   for (int base = 0; base < n; base += 32) {
     uint32_t mask = unit_mask(sc.units + base, o, d, Dm);
+#ifdef MIPT_EXP_ONE_CAND
+    mask &= 0u - mask;  // timing experiment only: wrong results
+#endif
     prof.mark(PF_PHASE1);
     prof.count(PF_N_QUERIES, 1u);
     prof.count(PF_N_CANDS, (uint32_t)__popc(mask));
@@ -399,7 +415,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_BATCH_OCC void k_bvh_batch(DeviceScene 
 
 template <int RNG_MODE, bool STATS, bool LIST, int KIND>
 __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a) {
-  extern __shared__ uint32_t lds_stack[];  // [max_depth][BLOCK] tags, then sphere normals
+  extern __shared__ uint32_t lds_stack[];  // vertex stack(s) of tags, sphere normals, record tables
   const int tid = threadIdx.x;
   const MiptParams& P = a.p;
   const int W = P.width, H = P.height;
@@ -411,9 +427,18 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   uint32_t s = 0, s_end = 0, pixel = 0, pkey = 0;
   size_t list_i = 0;
   // State a lane touches only when an item or a path begins or ends is parked in LDS, not in
-  // registers: the item's radiance sum and output slot, the last segment's direction and the
-  // terminal vertex' radiance between the terminal vertex and the end of the path.
-  __shared__ float park[12][BLOCK];
+  // registers. Rows of `park`, for context c = 0, 1 of the lane's radiance sum and buffer b = 0, 1
+  // of its vertex stack:
+  //   11 c + 0..2   radiance sum of the work item
+  //   11 c + 3      the item's output slot (index into a.partial, divided by 3)
+  //   11 b + 4..7   direction of the path's last segment
+  //   11 b + 8..10  terminal vertex: clamped cosine to the light, distance to the light, primitive
+  // Linear-scan scenes without spheres use both sets (deferred completion, below), the others one.
+  typedef typename TagType<KIND>::T TagT;
+  constexpr uint32_t TAGV_GLASS = (uint32_t)(TagT)TAG_GLASS, TAGV_FOG = (uint32_t)(TagT)TAG_FOG;
+  constexpr bool DEFER_KIND = KIND != SCENE_BVH;
+  const bool defer = paths_deferred(KIND, a.sc.n_spheres);  // wave-uniform
+  __shared__ float park[DEFER_KIND ? 22 : 11][BLOCK];
   bool have = false;
   if (LIST) {
     list_i = (size_t)blockIdx.x * BLOCK + tid;
@@ -443,8 +468,16 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   int depth = 0, sp = 0;
   bool shadow = false, fresh = true;
   float shadow_max = 0.f;
-  uint32_t* tags = lds_stack;
-  float* sph_n = reinterpret_cast<float*>(lds_stack + (size_t)P.max_depth * BLOCK);
+  // Completion state: which stack buffer the running path writes (cur), which sum context its item
+  // uses (ctx), and the lane's deferred job, if any: a path that ended lit, waiting for its
+  // radiance to be computed and added (its stack depth, its sum context, whether it was the last
+  // path of its item).
+  // Packed into one register: bit 0 cur, bit 1 ctx, bit 2 job pending, bit 3 the job's context,
+  // bit 4 the job is the last path of its item, bits 8.. the job's stack depth.
+  uint32_t js = 0;
+  constexpr uint32_t JS_CUR = 1u, JS_CTX = 2u, JS_PEND = 4u, JS_JCTX = 8u, JS_LAST = 16u;
+  TagT* tags = reinterpret_cast<TagT*>(lds_stack);
+  float* sph_n = reinterpret_cast<float*>(lds_stack + a.lds_sph_off);
   const bool fog = P.fog_sigma_t > 0.f;
   constexpr bool BVH = KIND == SCENE_BVH;
   BvhTrav trav;      // tree scenes: the lane's walk, resumable across iterations of the main loop
@@ -513,10 +546,12 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
               s = a.sample_begin + sb * a.item_samples;
               const uint32_t last = a.sample_begin + a.sample_count;
               s_end = (s + a.item_samples < last) ? s + a.item_samples : last;
-              const size_t slot = ((size_t)sb * ((size_t)W * H) + pixel) * 3;  // index into a.partial
-              park[10][tid] = __uint_as_float((uint32_t)slot);
-              park[11][tid] = __uint_as_float((uint32_t)(slot >> 32));
-              park[0][tid] = 0.f; park[1][tid] = 0.f; park[2][tid] = 0.f;
+              // a new item takes the lane's other sum context: the previous item's may still wait
+              // for a deferred job (that job is flushed before a third item could need it again)
+              if (defer) js ^= JS_CTX;
+              const int c0 = (js & JS_CTX) ? 11 : 0;
+              park[c0 + 3][tid] = __uint_as_float(sb * (uint32_t)(W * H) + pixel);  // < n_items: fits 32 bits
+              park[c0 + 0][tid] = 0.f; park[c0 + 1][tid] = 0.f; park[c0 + 2][tid] = 0.f;
               fresh = true;
               have = true;
             }
@@ -526,9 +561,11 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
         }
       }
     }
+    bool final_round = false;
     if (!__any(have)) {
-      if (drained) break;
-      continue;
+      if (!drained) continue;
+      if (!__any((js & JS_PEND) != 0)) break;
+      final_round = true;  // no work left: one more pass for the deferred jobs
     }
     prof.mark(PF_QUEUE);
     // A lane is `ready` for shading when its scene query has an answer. The linear scan answers
@@ -585,15 +622,14 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       ready = true;
     }
     }  // if (have)
+    bool path_done = false;
+    bool lit = false;  // the path ended at a terminal vertex the light reaches: a job for the completion below
     if (ready) {
     if (STATS || LIST) st[shadow ? ST_SHADOW : ST_CLOSEST]++;
 
-    bool path_done = false;
-    float cr = 0.f, cg = 0.f, cb = 0.f;  // radiance at the deepest vertex when the path ends lit
-
     if (shadow) {
       // light.cpp:26-29: occluded -> zero
-      if (h.idx == 0) { cr = park[7][tid]; cg = park[8][tid]; cb = park[9][tid]; }
+      lit = h.idx == 0;
       path_done = true;
     } else {
       V4 pos = {0, 0, 0, 0}, nrm = {0, 0, 0, 0};
@@ -645,51 +681,38 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
         const bool terminal = depth >= P.max_depth || rng_next<RNG_MODE>(rng) <= P.rr_prob;  // :80
         prof.mark(PF_HIT);
         if (terminal) {
-          // pathtracer.cpp:81-93 + directLight (light.cpp:13-31)
+          // pathtracer.cpp:81-93 + directLight (light.cpp:13-31). Only what the shadow ray needs
+          // is computed here: the light's radiance at this vertex (inverse square law, fog
+          // transmittance, albedo) is evaluated when the path is completed, and only if the shadow
+          // ray came through.
           V4 lp;
           lp.x = a.light_pos[0] + (rng_next<RNG_MODE>(rng) * 2.0f - 1.0f) * 0.1f;
           lp.y = a.light_pos[1];
           lp.z = a.light_pos[2] + (rng_next<RNG_MODE>(rng) * 2.0f - 1.0f) * 0.1f;
           lp.w = a.light_pos[3];
           const V4 at = medium ? o : pos;
-          float Lr, Lg, Lb;
           const V4 v = sub4(lp, at);
           const V4 vecr = normalize4(v);
           const float r = sqrtf(dot4(v, v));
-          const float den = (float)(((4.0 * 3.14159) * (double)r) * (double)r);  // light.cpp:22
-          const float tr = fog ? fog_expf(-(P.fog_sigma_t * r)) : 1.0f;  // transmittance to the light
+          float m = 1.0f;
           if (!medium) {
             // normalize(inter.normal) (light.cpp:20) is a per-triangle constant
             const V4 nn = sphere_hit ? normalize4(nrm) : V4{sh.nnx, sh.nny, sh.nnz, sh.nnw};
             const float c = dot4(vecr, nn);
-            const float m = (c < 0.f) ? 0.f : c;  // std::max(c, 0.f)
-            Lr = (a.light_col[0] * m) / den;
-            if (a.light_gray) {
-              Lg = Lr; Lb = Lr;
-            } else {
-              Lg = (a.light_col[1] * m) / den;
-              Lb = (a.light_col[2] * m) / den;
-            }
-            if (fog) { Lr = Lr * tr; Lg = Lg * tr; Lb = Lb * tr; }
-            if (sh.material != MIPT_MAT_GLASS) {  // pathtracer.cpp:88-93
-              Lr = (sh.r * Lr) * 1.0f; Lg = (sh.g * Lg) * 1.0f; Lb = (sh.b * Lb) * 1.0f;
-            }
+            m = (c < 0.f) ? 0.f : c;  // std::max(c, 0.f)
             o = add4(pos, scale4(vecr, 0.001f));  // light.cpp:25
-          } else {
-            const float phase = 1.0f / (4.0f * 3.14159f);
-            Lr = (((a.light_col[0] * phase) / den) * tr) * P.fog_albedo;
-            Lg = (((a.light_col[1] * phase) / den) * tr) * P.fog_albedo;
-            Lb = (((a.light_col[2] * phase) / den) * tr) * P.fog_albedo;
           }
-          park[3][tid] = d.x; park[4][tid] = d.y; park[5][tid] = d.z; park[6][tid] = d.w;  // last segment
-          park[7][tid] = Lr; park[8][tid] = Lg; park[9][tid] = Lb;
+          const int t0 = (js & JS_CUR) ? 15 : 4;
+          park[t0 + 0][tid] = d.x; park[t0 + 1][tid] = d.y; park[t0 + 2][tid] = d.z; park[t0 + 3][tid] = d.w;  // last segment
+          park[t0 + 4][tid] = m; park[t0 + 5][tid] = r;
+          park[t0 + 6][tid] = __uint_as_float(medium ? TERMINAL_IN_MEDIUM : (uint32_t)h.idx);
           nd = vecr; renorm = true;  // Ray ctor normalises again (ray.h:11-12)
           shadow_max = r;
           shadow = true;
           // A terminal vertex the light does not reach (cosine <= 0) has L = 0 whatever the
           // shadow ray finds, and existsIntersection draws no random numbers: the path ends here
           // with the radiance the reference computes. The counting variants still cast the ray.
-          if (!STATS && !LIST && Lr == 0.f && Lg == 0.f && Lb == 0.f) { path_done = true; shadow = false; }
+          if (!STATS && !LIST && !medium && m == 0.f) { path_done = true; shadow = false; }
           prof.mark(PF_TERMINAL);
         } else if (medium) {
           // isotropic scattering, weight = single-scattering albedo
@@ -700,7 +723,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           sc_r = sqrtf(s2 < 0.f ? 0.f : s2);
           sc_phi = 6.28318530718f * u2;
           need_sc = true; scatter = true;
-          tags[sp * BLOCK + tid] = TAG_FOG;
+          tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + sp)) * BLOCK + tid] = (TagT)TAG_FOG;
           sp++; depth++;
           prof.mark(PF_SCATTER);
         } else {
@@ -717,7 +740,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
             sc_r = sqrtf(1.0f - sc_y * sc_y);
             sc_phi = (float)((2 * 3.14) * (double)ub);
             need_sc = true;
-            tags[sp * BLOCK + tid] = (uint32_t)h.idx;
+            tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + sp)) * BLOCK + tid] = (TagT)h.idx;
             if (sphere_hit) {
               float* q = sph_n + ((size_t)sp * BLOCK + tid) * 4;
               q[0] = nrm.x; q[1] = nrm.y; q[2] = nrm.z; q[3] = nrm.w;
@@ -752,11 +775,12 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
               nd = add4(d, scale4(n, cost1 * 2.0f));
             }
             renorm = true;
-            tags[sp * BLOCK + tid] = TAG_GLASS;
+            tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + sp)) * BLOCK + tid] = (TagT)TAG_GLASS;
             sp++; depth++;
             prof.mark(PF_GLASS);
           } else if (mat == MIPT_MAT_SPECULAR) {
             // bounceSpecular (pathtracer.cpp:65-70); weight 1
+            if (STATS) st[ST_SPECULAR]++;
             const float k2 = dot4(d, nrm) * 2.f;
             nd = sub4(d, scale4(nrm, k2)); renorm = true;
             depth++;
@@ -785,16 +809,72 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
         prof.mark(PF_RENORM);
       }
     }
+    }  // if (ready)
 
-    if (path_done) {
-      if (cr != 0.f || cg != 0.f || cb != 0.f) {
+    // ---- completion of paths
+    // A path that ends lit still owes its radiance: the light at the terminal vertex, multiplied
+    // back through the vertices (the recursion unwound, deepest first) and added to the item's sum.
+    // Nothing the lane does next depends on that value, and at any moment only a few lanes of a
+    // wave have one to compute. So a lane leaves it behind as a JOB -- vertex stack and terminal
+    // record stay in the buffers it just used, the next path writes the other pair -- and starts
+    // its next path; the wave computes all its jobs together when some lane needs its second
+    // buffer back: it ends another lit path, or it is about to start an item on the sum context
+    // its job still adds to. A lane's jobs run in the order of its paths, so the item's sum is
+    // formed in sample order as before. Scenes with spheres or a tree keep one buffer and compute
+    // the job at once (their stacks are too large to double in LDS).
+    const bool want_job = path_done && lit;
+    const bool item_end = path_done && s + 1 >= s_end;
+    const bool pend = (js & JS_PEND) != 0;
+    // the job's sum context differs from the running item's (bits 3 and 1 of js)
+    const bool other_ctx = (((js >> 3) ^ (js >> 1)) & 1u) != 0;
+    bool flush;
+    if (defer) {
+      flush = __any(pend && path_done && (want_job || (item_end && other_ctx))) || final_round;
+    } else {
+      if (want_job) js = JS_PEND | ((uint32_t)sp << 8);  // one buffer, one context: all other bits stay 0
+      flush = __any((js & JS_PEND) != 0);
+    }
+    prof.count_wave(PF_N_ITERS);
+    if (flush) {
+      prof.count_wave(PF_N_FLUSH);
+      if (js & JS_PEND) {
+        prof.count(PF_N_JOBS, 1u);
+        prof.count(PF_N_JOB_LEVELS, js >> 8);
+        const int b = (defer && !(js & JS_CUR)) ? 1 : 0;  // the buffer the running path does not write
+        const int t0 = 11 * b + 4, c0 = (js & JS_JCTX) ? 11 : 0;
+        const int job_sp = (int)(js >> 8);
+        const V4 dfin = {park[t0 + 0][tid], park[t0 + 1][tid], park[t0 + 2][tid], park[t0 + 3][tid]};
+        const float m = park[t0 + 4][tid], r = park[t0 + 5][tid];
+        const uint32_t tprim = __float_as_uint(park[t0 + 6][tid]);
+        // directLight (light.cpp:20-24) and pathtracer.cpp:88-93
+        const float den = (float)(((4.0 * 3.14159) * (double)r) * (double)r);  // light.cpp:22
+        const float tr = fog ? fog_expf(-(P.fog_sigma_t * r)) : 1.0f;  // transmittance to the light
+        float cr, cg, cb;
+        if (tprim != TERMINAL_IN_MEDIUM) {
+          const ShadeRec sh = shade_tab[tprim];
+          cr = (a.light_col[0] * m) / den;
+          if (a.light_gray) {
+            cg = cr; cb = cr;
+          } else {
+            cg = (a.light_col[1] * m) / den;
+            cb = (a.light_col[2] * m) / den;
+          }
+          if (fog) { cr = cr * tr; cg = cg * tr; cb = cb * tr; }
+          if (sh.material != MIPT_MAT_GLASS) {  // pathtracer.cpp:88-93
+            cr = (sh.r * cr) * 1.0f; cg = (sh.g * cg) * 1.0f; cb = (sh.b * cb) * 1.0f;
+          }
+        } else {
+          const float phase = 1.0f / (4.0f * 3.14159f);
+          cr = (((a.light_col[0] * phase) / den) * tr) * P.fog_albedo;
+          cg = (((a.light_col[1] * phase) / den) * tr) * P.fog_albedo;
+          cb = (((a.light_col[2] * phase) / den) * tr) * P.fog_albedo;
+        }
         // unwind the recursion, deepest vertex first
-        const V4 dfin = {park[3][tid], park[4][tid], park[5][tid], park[6][tid]};
-        for (int k = sp - 1; k >= 0; --k) {
-          const uint32_t tag = tags[k * BLOCK + tid];
-          if (tag == TAG_GLASS) {  // pathtracer.cpp:62
+        for (int k = job_sp - 1; k >= 0; --k) {
+          const uint32_t tag = tags[((size_t)(b * P.max_depth + k)) * BLOCK + tid];
+          if (tag == TAGV_GLASS) {  // pathtracer.cpp:62
             cr = (cr * 1.0f) * P.glass_weight; cg = (cg * 1.0f) * P.glass_weight; cb = (cb * 1.0f) * P.glass_weight;
-          } else if (tag == TAG_FOG) {
+          } else if (tag == TAGV_FOG) {
             cr = cr * P.fog_albedo; cg = cg * P.fog_albedo; cb = cb * P.fog_albedo;
           } else {  // pathtracer.cpp:18, with the direction of the last segment
             const ShadeRec sv = shade_tab[tag];
@@ -809,20 +889,34 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
             cb = (((cb * sv.b) * dn) * 1.0f) * P.diffuse_weight;
           }
         }
-        park[0][tid] += cr; park[1][tid] += cg; park[2][tid] += cb;  // main.cpp:137
+        const float sr = park[c0 + 0][tid] + cr, sg = park[c0 + 1][tid] + cg, sb = park[c0 + 2][tid] + cb;  // main.cpp:137
+        park[c0 + 0][tid] = sr; park[c0 + 1][tid] = sg; park[c0 + 2][tid] = sb;
+        if (js & JS_LAST) {  // the job's item was waiting for this path alone
+          float* dst = a.partial + (size_t)__float_as_uint(park[c0 + 3][tid]) * 3;
+          dst[0] = sr; dst[1] = sg; dst[2] = sb;
+        }
+        js &= JS_CUR | JS_CTX;
       }
+    }
+    if (defer && want_job)  // the path's buffers become the job's; the next path writes the other pair
+      js = ((js & (JS_CUR | JS_CTX)) ^ JS_CUR) | JS_PEND | ((js & JS_CTX) ? JS_JCTX : 0u) | ((uint32_t)sp << 8);
+    if (path_done) {
       s++;
       fresh = true;
       if (s >= s_end) {
         // the item's samples were added in sample order by this one lane: plain store
         have = false;
         if (!LIST) {
-          float* dst = a.partial + (((size_t)__float_as_uint(park[11][tid]) << 32) | (size_t)__float_as_uint(park[10][tid]));
-          dst[0] = park[0][tid]; dst[1] = park[1][tid]; dst[2] = park[2][tid];
+          if ((js & JS_PEND) && (((js >> 3) ^ (js >> 1)) & 1u) == 0) {
+            js |= JS_LAST;  // the sum is complete once the job has run
+          } else {
+            const int c0 = (js & JS_CTX) ? 11 : 0;
+            float* dst = a.partial + (size_t)__float_as_uint(park[c0 + 3][tid]) * 3;
+            dst[0] = park[c0 + 0][tid]; dst[1] = park[c0 + 1][tid]; dst[2] = park[c0 + 2][tid];
+          }
         }
       }
     }
-    }  // if (ready)
     prof.mark(PF_UNWIND);
   }
 #ifdef MIPT_PROFILE_SECTIONS

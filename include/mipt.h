@@ -143,6 +143,7 @@ typedef struct MiptStats {
   uint64_t bvh_overflow;    /* LBVH scenes: rays whose stack / hit list overflowed (must be 0) */
   uint64_t bvh_nodes;       /* LBVH scenes: four-wide nodes fetched (tri_tests then counts leaves visited) */
   double kernel_ms;        /* device time of the last render call's path kernel */
+  uint64_t specular_bounces; /* bounceSpecular calls */
 } MiptStats;
 
 typedef struct MiptScene MiptScene; /* opaque */

@@ -302,7 +302,7 @@ typedef struct {
 
 typedef struct {
   uint64_t closest_rays, shadow_rays, tri_tests, gate_passes, sphere_tests, fog_events;
-  uint64_t diffuse_bounces, mirror_bounces, glass_bounces;
+  uint64_t diffuse_bounces, mirror_bounces, glass_bounces, specular_bounces;
 } OrCounters;
 
 /* solveQuadratic (utils.cpp:34-49). The 0.5 literals are double, sqrt is the float overload. */
@@ -658,7 +658,7 @@ static void trace(const OrCtx* cx, float o[4], float d[4], int depth, float colo
     case MIPT_MAT_DIFFUSE: cx->cn->diffuse_bounces++; bounce_diffuse(cx, o, d, depth, color, &hit); break;
     case MIPT_MAT_MIRROR: cx->cn->mirror_bounces++; bounce_mirror(cx, o, d, depth, color, hit.normal); break;
     case MIPT_MAT_GLASS: cx->cn->glass_bounces++; bounce_glass(cx, o, d, depth, color, hit.normal); break;
-    case MIPT_MAT_SPECULAR: bounce_specular(cx, o, d, depth, color, hit.normal); break;
+    case MIPT_MAT_SPECULAR: cx->cn->specular_bounces++; bounce_specular(cx, o, d, depth, color, hit.normal); break;
     default: break;
   }
 }
@@ -780,7 +780,7 @@ int or_render_accumulate(const MiptTriangle* tris, size_t n_tris, const MiptSphe
         total.tri_tests += local.tri_tests; total.gate_passes += local.gate_passes;
         total.sphere_tests += local.sphere_tests; total.fog_events += local.fog_events;
         total.diffuse_bounces += local.diffuse_bounces; total.mirror_bounces += local.mirror_bounces;
-        total.glass_bounces += local.glass_bounces;
+        total.glass_bounces += local.glass_bounces; total.specular_bounces += local.specular_bounces;
       }
     }
   }
@@ -791,7 +791,7 @@ int or_render_accumulate(const MiptTriangle* tris, size_t n_tris, const MiptSphe
     stats->tri_tests = total.tri_tests; stats->gate_passes = total.gate_passes;
     stats->sphere_tests = total.sphere_tests; stats->fog_events = total.fog_events;
     stats->diffuse_bounces = total.diffuse_bounces; stats->mirror_bounces = total.mirror_bounces;
-    stats->glass_bounces = total.glass_bounces;
+    stats->glass_bounces = total.glass_bounces; stats->specular_bounces = total.specular_bounces;
   }
   return 0;
 }

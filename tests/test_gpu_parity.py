@@ -375,6 +375,32 @@ def test_production_kernel_equals_counting_kernel(api, O, pkg, scene, fog):
     sc.close()
 
 
+def test_specular_material_on_a_linear_scan_scene(api, O, pkg):
+    # bounceSpecular (pathtracer.cpp:65-70): no shipped scene assigns "specular"; here the tall block
+    # of the Cornell model carries it. Counted and compared with the oracle, paths bit for bit.
+    tris = O.load_test_model(0).copy()
+    tris["material"][20:30] = pkg.abi.MAT_SPECULAR
+    W, H = 64, 48
+    cam, light = O.default_camera(W), O.default_light(False)
+    sc = api.Scene(tris)
+    assert not sc.bvh_info()[0]
+    p = O.default_params(W, H, seed=13, flags=pkg.abi.FLAG_STATS)
+    img = sc.render_accumulate(cam, light, p, 0, 8)
+    st = sc.stats()
+    ref, ost = O.render_accumulate(tris, None, cam, light, p, 0, 8)
+    assert st.specular_bounces == ost.specular_bounces and st.specular_bounces > 500
+    for k in ("closest_rays", "shadow_rays", "diffuse_bounces", "mirror_bounces", "glass_bounces"):
+        assert getattr(st, k) == getattr(ost, k), k
+    assert np.array_equal(bits(img), bits(ref))
+    plain = sc.render_accumulate(cam, light, O.default_params(W, H, seed=13), 0, 8)
+    assert np.array_equal(bits(plain), bits(img))
+    px, py, smp = path_list(W, H, 4000, 8)
+    rgb, counts = sc.trace_paths(cam, light, p, px, py, smp)
+    orgb, ocounts = O.trace_paths(tris, None, cam, light, p, px, py, smp)
+    assert np.array_equal(counts, ocounts) and np.array_equal(bits(rgb), bits(orgb))
+    sc.close()
+
+
 def test_progressive_frame_equals_host_round_trips(api, O):
     # pixels + samplesSeenSoFar resident on the device: same sums and the same ARGB screen as
     # render_accumulate / resolve_argb through host buffers; reset starts over

@@ -37,7 +37,7 @@ def test_struct_layouts(pkg):
     assert C.sizeof(abi.MiptCamera) == 4 * (1 + 4 + 16 + 16)
     assert C.sizeof(abi.MiptLight) == 28
     assert C.sizeof(abi.MiptParams) == 52
-    assert C.sizeof(abi.MiptStats) == 112
+    assert C.sizeof(abi.MiptStats) == 120
 
 
 @pytest.mark.parametrize("which,name", [(0, "cornell"), (1, "colorbleeding"), (2, "glasscube"), (3, "none")])
