@@ -15,6 +15,7 @@ MIPT_E_INVALID = -1
 MIPT_E_HIP = -2
 MIPT_E_NOMEM = -3
 MIPT_E_UNSUPPORTED = -4
+MIPT_E_RCCL = -5
 
 MAT_DIFFUSE, MAT_MIRROR, MAT_GLASS, MAT_SPECULAR, MAT_NONE = range(5)
 MATERIAL_NAMES = {"diffuse": MAT_DIFFUSE, "mirror": MAT_MIRROR, "glass": MAT_GLASS,
@@ -88,6 +89,8 @@ EXPORTS = [
     "mipt_load_test_model", "mipt_default_camera", "mipt_default_light", "mipt_debug_selfcheck", "mipt_scene_has_bvh", "mipt_scene_pair_units", "mipt_scene_axis_pair_units", "mipt_load_obj", "mipt_normalise_triangles", "mipt_save_bmp", "mipt_frame_create", "mipt_frame_destroy", "mipt_frame_reset",
     "mipt_frame_add_samples", "mipt_frame_present", "mipt_frame_read_pixels", "mipt_frame_samples",
     "mipt_render_accumulate_noalloc_dev", "mipt_scene_create_opts",
+    "mipt_multi_create", "mipt_multi_destroy", "mipt_multi_device_count", "mipt_multi_render_accumulate",
+    "mipt_multi_sample_range", "mipt_multi_scene",
 ]
 
 
@@ -135,6 +138,16 @@ def load_library(path=None):
     lib.mipt_resolve_argb_dev.argtypes = [vp, f32p, C.c_int, C.c_int, C.c_uint32, u32p, vp]
     lib.mipt_render_accumulate_noalloc_dev.argtypes = lib.mipt_render_accumulate_dev.argtypes
     lib.mipt_get_stats.argtypes = [vp, P(MiptStats)]
+    lib.mipt_multi_create.argtypes = [vp, C.c_size_t, vp, C.c_size_t, P(C.c_int), C.c_int, P(vp)]
+    lib.mipt_multi_destroy.argtypes = [vp]
+    lib.mipt_multi_destroy.restype = None
+    lib.mipt_multi_device_count.argtypes = [vp]
+    lib.mipt_multi_scene.argtypes = [vp, C.c_int]
+    lib.mipt_multi_scene.restype = vp
+    lib.mipt_multi_render_accumulate.argtypes = [vp, P(MiptCamera), P(MiptLight), P(MiptParams),
+                                                 C.c_uint32, C.c_uint32, f32p]
+    lib.mipt_multi_sample_range.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, P(C.c_uint32), P(C.c_uint32)]
+    lib.mipt_multi_sample_range.restype = None
     lib.mipt_path_key.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     lib.mipt_path_key.restype = C.c_uint32
     lib.mipt_debug_selfcheck.argtypes = [vp, C.c_uint64, C.c_uint32, P(C.c_uint64 * 8)]

@@ -299,3 +299,52 @@ class Frame:
         acc = np.zeros((self.width, self.height, 3), dtype=np.float32)
         _check(self._lib.mipt_frame_read_pixels(self._h, _ptr(acc)))
         return acc
+
+
+class MultiScene:
+    """The scene replicated on several GPUs of one node, driven from this one process: render_accumulate
+    splits the sample range over the devices and sums the per-device images with one RCCL reduce
+    (mipt_multi_*; replaces the OpenMP loop of main.cpp:121)."""
+
+    def __init__(self, tris, spheres=None, devices=(0,)):
+        self._lib = abi.load_library()
+        tris = np.ascontiguousarray(tris, dtype=abi.TRIANGLE_DTYPE)
+        ns = 0 if spheres is None else len(spheres)
+        if ns:
+            spheres = np.ascontiguousarray(spheres, dtype=abi.SPHERE_DTYPE)
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(self._lib.mipt_multi_create(_ptr(tris) if len(tris) else None, len(tris),
+                                           _ptr(spheres) if ns else None, ns, devs, len(devices), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mipt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_count(self):
+        return int(self._lib.mipt_multi_device_count(self._h))
+
+    def render_accumulate(self, cam, light, params, sample_begin, sample_count, accum=None):
+        W, H = params.width, params.height
+        if accum is None:
+            accum = np.zeros((W, H, 3), dtype=np.float32)
+        if accum.dtype != np.float32 or accum.shape != (W, H, 3) or not accum.flags.c_contiguous:
+            raise ValueError("accum must be a C-contiguous float32 (W, H, 3) array")
+        _check(self._lib.mipt_multi_render_accumulate(self._h, C.byref(cam), C.byref(light), C.byref(params),
+                                                      sample_begin, sample_count, _ptr(accum)))
+        return accum
+
+
+def multi_sample_range(begin, count, rank, n):
+    b, c = C.c_uint32(), C.c_uint32()
+    abi.load_library().mipt_multi_sample_range(begin, count, rank, n, C.byref(b), C.byref(c))
+    return int(b.value), int(c.value)

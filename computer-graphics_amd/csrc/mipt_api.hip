@@ -36,9 +36,11 @@ static int fail(int code, const char* fmt, ...) {
 #define HIP_TRY(call)                                                                           \
   do {                                                                                          \
     hipError_t e_ = (call);                                                                     \
-    if (e_ != hipSuccess)                                                                       \
+    if (e_ != hipSuccess) {                                                                     \
+      (void)hipGetLastError(); /* reported here: must not surface again after a later launch */ \
       return fail(e_ == hipErrorOutOfMemory ? MIPT_E_NOMEM : MIPT_E_HIP, "%s failed: %s", #call, \
                   hipGetErrorString(e_));                                                       \
+    }                                                                                           \
   } while (0)
 
 extern "C" const char* mipt_last_error(void) { return g_err; }
@@ -119,6 +121,7 @@ static void scene_free(MiptScene* s) {
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->ev_busy) (void)hipEventDestroy(s->ev_busy);
+  (void)hipGetLastError();  // a failure while tearing down is not the next call's error
   delete s;
 }
 
@@ -1095,6 +1098,7 @@ extern "C" void mipt_frame_destroy(MiptFrame* f) {
   if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
   if (f->d_accum) (void)hipFree(f->d_accum);
   if (f->d_screen) (void)hipFree(f->d_screen);
+  (void)hipGetLastError();
   delete f;
 }
 

@@ -173,6 +173,59 @@ inline void Draw(GpuScene& gpu, ScreenT* screen, const CameraT& cam, const Light
   check(mipt_resolve_argb(gpu.handle(), accum.data(), W, H, (uint32_t)samplesSeenSoFar, screen->buffer));
 }
 
+// The scene on several GPUs of the node, driven from this one process: what the OpenMP loop over
+// image columns (main.cpp:121) becomes. Draw() below splits every call's samples over the devices;
+// the library sums the per-device images with one RCCL reduce.
+class MultiGpuScene {
+ public:
+  template <class TriangleT, class SphereT>
+  MultiGpuScene(const std::vector<TriangleT>& triangles, const std::vector<SphereT>& spheres,
+                const std::vector<int>& devices) {
+    std::vector<MiptTriangle> t;
+    std::vector<MiptSphere> s;
+    t.reserve(triangles.size());
+    for (const auto& x : triangles) t.push_back(to_mipt(x));
+    for (const auto& x : spheres) s.push_back(to_mipt_sphere(x));
+    check(mipt_multi_create(t.data(), t.size(), s.data(), s.size(), devices.data(), (int)devices.size(), &h_));
+  }
+  ~MultiGpuScene() { mipt_multi_destroy(h_); }
+  MultiGpuScene(const MultiGpuScene&) = delete;
+  MultiGpuScene& operator=(const MultiGpuScene&) = delete;
+  MiptMulti* handle() const { return h_; }
+  MiptParams params;
+  bool params_set = false;
+
+ private:
+  MiptMulti* h_ = nullptr;
+};
+
+// Draw (main.cpp:110-146) on all the scene's GPUs
+template <class ScreenT, class CameraT, class LightT, class Vec3T>
+inline void Draw(MultiGpuScene& gpu, ScreenT* screen, const CameraT& cam, const LightT& light, Vec3T** pixels,
+                 int& samplesSeenSoFar, int samples_per_call = 64) {
+  const int W = screen->width, H = screen->height;
+  if (!gpu.params_set) { mipt_params_default(&gpu.params, W, H); gpu.params_set = true; }
+  gpu.params.width = W; gpu.params.height = H;
+  std::vector<float> accum((size_t)W * H * 3);
+  for (int x = 0; x < W; ++x)
+    for (int y = 0; y < H; ++y) {
+      float* a = &accum[((size_t)x * H + y) * 3];
+      a[0] = pixels[x][y].x; a[1] = pixels[x][y].y; a[2] = pixels[x][y].z;
+    }
+  const MiptCamera c = to_mipt_camera(cam);
+  const MiptLight l = to_mipt_light(light);
+  check(mipt_multi_render_accumulate(gpu.handle(), &c, &l, &gpu.params, (uint32_t)samplesSeenSoFar,
+                                     (uint32_t)samples_per_call, accum.data()));
+  samplesSeenSoFar += samples_per_call;
+  for (int x = 0; x < W; ++x)
+    for (int y = 0; y < H; ++y) {
+      const float* a = &accum[((size_t)x * H + y) * 3];
+      pixels[x][y].x = a[0]; pixels[x][y].y = a[1]; pixels[x][y].z = a[2];
+    }
+  check(mipt_resolve_argb(mipt_multi_scene(gpu.handle(), 0), accum.data(), W, H, (uint32_t)samplesSeenSoFar,
+                          screen->buffer));
+}
+
 // The interactive loop of main.cpp:98-103 with the image kept on the device: `pixels` and
 // `samplesSeenSoFar` become one Frame; only the ARGB screen crosses PCIe per frame.
 //     mipt_host::Frame frame(*gpu, SCREEN_WIDTH, SCREEN_HEIGHT);

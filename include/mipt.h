@@ -37,7 +37,8 @@ typedef enum MiptError {
   MIPT_E_INVALID = -1,     /* bad argument (null pointer, size out of range, unsupported mode) */
   MIPT_E_HIP = -2,         /* a HIP runtime call failed; mipt_last_error() names it */
   MIPT_E_NOMEM = -3,       /* host or device allocation failed */
-  MIPT_E_UNSUPPORTED = -4  /* valid request this build cannot serve (e.g. oracle-only RNG mode) */
+  MIPT_E_UNSUPPORTED = -4, /* valid request this build cannot serve (e.g. oracle-only RNG mode) */
+  MIPT_E_RCCL = -5         /* librccl.so could not be loaded, or a collective failed */
 } MiptError;
 
 /* Material of a primitive. The reference stores a `const char* type`
@@ -303,6 +304,29 @@ int mipt_frame_add_samples(MiptFrame* frame, const MiptCamera* cam, const MiptLi
 int mipt_frame_present(MiptFrame* frame, uint32_t* screen_buffer);
 int mipt_frame_read_pixels(MiptFrame* frame, float* accum_rgb);
 int mipt_frame_samples(const MiptFrame* frame); /* samplesSeenSoFar */
+
+/* Several GPUs of one node behind one render call, from ONE host process -- what replaces the
+ * reference's only parallel construct, `#pragma omp parallel for` over image columns (main.cpp:121).
+ * mipt_multi_create puts a replica of the scene on every listed device. mipt_multi_render_accumulate
+ * is mipt_render_accumulate (host accumulation buffer, samples ADDED): the sample range is split into
+ * contiguous parts, one per device (mipt_multi_sample_range; a path's random numbers depend on the
+ * global sample index only, so the parts are exactly the paths one GPU would trace), each device
+ * renders its part on its own stream, and ONE ncclReduce(sum, float32, 3 W H) over RCCL adds the
+ * per-device images on the first device. The image equals the single-GPU image up to the order of
+ * the float additions. librccl.so is loaded on first use; MIPT_E_RCCL if that or a collective fails. */
+typedef struct MiptMulti MiptMulti;
+int mipt_multi_create(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres, size_t n_spheres,
+                      const int* devices, int n_devices, MiptMulti** out);
+void mipt_multi_destroy(MiptMulti* multi);
+int mipt_multi_device_count(const MiptMulti* multi);
+/* the replica on the rank-th listed device (owned by `multi`), e.g. for mipt_resolve_argb; NULL if out of range */
+MiptScene* mipt_multi_scene(MiptMulti* multi, int rank);
+int mipt_multi_render_accumulate(MiptMulti* multi, const MiptCamera* cam, const MiptLight* light,
+                                 const MiptParams* params, uint32_t sample_begin, uint32_t sample_count,
+                                 float* accum_rgb);
+/* share of device `rank` out of `n`: contiguous, the first count % n ranks get one sample more */
+void mipt_multi_sample_range(uint32_t begin, uint32_t count, int rank, int n, uint32_t* part_begin,
+                             uint32_t* part_count);
 
 /* Counters of the most recent render / trace call made with MIPT_FLAG_STATS, and
  * the device time of its path kernel (measured with HIP events on the launch

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--fog", type=float, default=0.0)
     ap.add_argument("--flags", type=int, nargs="*", default=[0])
+    ap.add_argument("--no-batch", action="store_true", help="skip the closest-hit batch")
     args = ap.parse_args()
     import torch
     pkg = graft.load_package()
@@ -31,6 +32,9 @@ def main():
         sc.render_accumulate_dev(cam, light, p, 0, args.spp, acc)
         torch.cuda.synchronize()
         print(f"flags={flags} kernel_ms={sc.stats().kernel_ms:.3f}")
+    if args.no_batch:
+        sc.close()
+        return
     # incoherent closest-hit batch (scan only, no shading)
     import numpy as np
     rng = np.random.default_rng(0)
