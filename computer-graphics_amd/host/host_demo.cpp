@@ -3,11 +3,13 @@
 // `closestIntersection` for single rays and `Draw` into a `screen` buffer. The vector types below
 // carry the member names the reference's glm types have (glm itself is not needed here).
 //
-//   host_demo <scene 0..3> <size> <frames> <samples_per_frame>
+//   host_demo <scene 0..3> <size> <frames> <samples_per_frame> [multi]
+// (multi: Draw goes through mipt_host::MultiGpuScene on device 0 -- the several-GPU path with one rank)
 // prints one line of key=value results that tests/test_gpu_host_cpp.py compares with the
 // Python host's results for the same inputs.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "mipt_adapter.hpp"
@@ -36,6 +38,7 @@ int main(int argc, char** argv) {
   const int size = argc > 2 ? atoi(argv[2]) : 64;
   const int frames = argc > 3 ? atoi(argv[3]) : 2;
   const int spf = argc > 4 ? atoi(argv[4]) : 4;
+  const bool multi = argc > 5 && strcmp(argv[5], "multi") == 0;
   try {
     MiptTriangle raw[30];
     const int n = mipt_load_test_model(which, raw, 30);
@@ -83,7 +86,12 @@ int main(int argc, char** argv) {
     vec3** pixels = new vec3*[size];
     for (int x = 0; x < size; ++x) pixels[x] = new vec3[size]();
     int samplesSeenSoFar = 0;
-    for (int f = 0; f < frames; ++f) mipt_host::Draw(gpu, &scr, cam, light, pixels, samplesSeenSoFar, spf);
+    if (multi) {
+      mipt_host::MultiGpuScene all(triangles, spheres, std::vector<int>{0});
+      for (int f = 0; f < frames; ++f) mipt_host::Draw(all, &scr, cam, light, pixels, samplesSeenSoFar, spf);
+    } else {
+      for (int f = 0; f < frames; ++f) mipt_host::Draw(gpu, &scr, cam, light, pixels, samplesSeenSoFar, spf);
+    }
     double psum = 0;
     uint64_t ssum = 0;
     for (int x = 0; x < size; ++x)

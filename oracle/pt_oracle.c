@@ -721,7 +721,9 @@ int or_trace_paths(const MiptTriangle* tris, size_t n_tris, const MiptSphere* sp
   OrScene sc = {tris, n_tris, sph, n_sph};
   float M[16];
   or_mat4_mul(cam->rot_x, cam->rot_y, M); /* main.cpp:133 */
-  for (size_t i = 0; i < n_paths; i++) {
+  /* listed paths are independent (own engine, own counters): spread over the host threads */
+#pragma omp parallel for schedule(dynamic, 64)
+  for (long long i = 0; i < (long long)n_paths; i++) {
     OrCounters cn;
     memset(&cn, 0, sizeof cn);
     OrRng rng = {params->rng_mode, 1u, 0u, 0u};

@@ -52,11 +52,11 @@ def test_adapter_accepts_reference_types(tmp_path, pkg, O):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which,size,frames,spf", [(2, 64, 2, 4), (0, 48, 3, 2)])
-def test_host_demo_matches_python_host(pkg, which, size, frames, spf):
+@pytest.mark.parametrize("which,size,frames,spf,mode", [(2, 64, 2, 4, ""), (0, 48, 3, 2, ""), (2, 56, 2, 3, "multi")])
+def test_host_demo_matches_python_host(pkg, which, size, frames, spf, mode):
     exe = os.path.join(ROOT, "computer-graphics_amd", "host", "host_demo")
     assert os.path.exists(exe), "host_demo is built by __graft_entry__.build()"
-    out = subprocess.run([exe, str(which), str(size), str(frames), str(spf)], check=True,
+    out = subprocess.run([exe, str(which), str(size), str(frames), str(spf)] + ([mode] if mode else []), check=True,
                          capture_output=True, text=True).stdout.strip().splitlines()[-1]
     kv = dict(item.split("=") for item in out.split())
     api, abi = pkg.api, pkg.abi
