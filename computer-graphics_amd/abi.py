@@ -90,7 +90,7 @@ EXPORTS = [
     "mipt_frame_add_samples", "mipt_frame_present", "mipt_frame_read_pixels", "mipt_frame_samples",
     "mipt_render_accumulate_noalloc_dev", "mipt_scene_create_opts",
     "mipt_multi_create", "mipt_multi_destroy", "mipt_multi_device_count", "mipt_multi_render_accumulate",
-    "mipt_multi_sample_range", "mipt_multi_scene",
+    "mipt_multi_sample_range", "mipt_multi_scene", "mipt_frame_poll",
 ]
 
 
@@ -163,6 +163,7 @@ def load_library(path=None):
     lib.mipt_frame_present.argtypes = [vp, vp]
     lib.mipt_frame_read_pixels.argtypes = [vp, vp]
     lib.mipt_frame_samples.argtypes = [vp]
+    lib.mipt_frame_poll.argtypes = [vp]
     lib.mipt_load_obj.argtypes = [C.c_char_p, vp, C.c_size_t]
     lib.mipt_normalise_triangles.argtypes = [vp, C.c_size_t, C.c_float, P(C.c_float * 3), P(C.c_float * 3),
                                              P(C.c_float * 3), C.c_uint32]

@@ -284,6 +284,13 @@ class Frame:
     def samples(self):
         return int(self._lib.mipt_frame_samples(self._h))
 
+    def poll(self):
+        """True when every sample added so far has been rendered (non-blocking)."""
+        rc = self._lib.mipt_frame_poll(self._h)
+        if rc < 0:
+            _check(rc)
+        return rc == 1
+
     def reset(self):
         _check(self._lib.mipt_frame_reset(self._h))
 

@@ -1168,6 +1168,16 @@ extern "C" int mipt_frame_read_pixels(MiptFrame* f, float* accum_rgb) {
 
 extern "C" int mipt_frame_samples(const MiptFrame* f) { return f ? (int)f->samples : 0; }
 
+extern "C" int mipt_frame_poll(MiptFrame* f) {
+  if (!f) return fail(MIPT_E_INVALID, "mipt_frame_poll: frame is null");
+  HIP_TRY(hipSetDevice(f->device));
+  const hipError_t e = hipStreamQuery(f->stream);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+  (void)hipGetLastError();
+  return fail(MIPT_E_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+}
+
 extern "C" int mipt_debug_selfcheck(MiptScene* s, uint64_t n_rays, uint32_t seed, uint64_t out[8]) {
   if (!s || !out) return fail(MIPT_E_INVALID, "mipt_debug_selfcheck: null argument");
   if (n_rays > ((uint64_t)1 << 36)) return fail(MIPT_E_INVALID, "mipt_debug_selfcheck: at most 2^36 rays per call");

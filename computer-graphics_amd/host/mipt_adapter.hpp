@@ -253,6 +253,11 @@ class Frame {
   }
   template <class ScreenT> void present(ScreenT* screen) { check(mipt_frame_present(f_, screen->buffer)); }
   int samplesSeenSoFar() const { return mipt_frame_samples(f_); }
+  bool done() {  // non-blocking: have all samples added so far been rendered?
+    const int rc = mipt_frame_poll(f_);
+    if (rc < 0) check(rc);
+    return rc == 1;
+  }
 
  private:
   GpuScene& gpu_;

@@ -304,6 +304,10 @@ int mipt_frame_add_samples(MiptFrame* frame, const MiptCamera* cam, const MiptLi
 int mipt_frame_present(MiptFrame* frame, uint32_t* screen_buffer);
 int mipt_frame_read_pixels(MiptFrame* frame, float* accum_rgb);
 int mipt_frame_samples(const MiptFrame* frame); /* samplesSeenSoFar */
+/* Non-blocking: 1 when every sample added so far has been rendered (mipt_frame_present would not
+ * wait), 0 while the GPU is still at it, or a MiptError. Lets the event loop of main.cpp:98-103 keep
+ * handling input (Update / handleKeyboard) while a long add_samples call runs. */
+int mipt_frame_poll(MiptFrame* frame);
 
 /* Several GPUs of one node behind one render call, from ONE host process -- what replaces the
  * reference's only parallel construct, `#pragma omp parallel for` over image columns (main.cpp:121).

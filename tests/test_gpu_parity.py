@@ -424,7 +424,12 @@ def test_progressive_frame_equals_host_round_trips(api, O):
     assert np.array_equal(screen, sc.resolve_argb(acc, 12))
     fr.reset()
     assert fr.samples == 0 and not fr.read_pixels().any()
+    assert fr.poll()            # nothing queued
     fr.add_samples(cam, light, p, 12)
+    polls = 0
+    while not fr.poll():        # non-blocking: the host keeps its event loop going
+        polls += 1
+        assert polls < 10 ** 7
     whole = fr.read_pixels()
     assert np.allclose(whole, acc, rtol=2e-6, atol=1e-7)   # one call of 12 = 1 + 4 + 7 up to the order of the sums
     fr.close()
