@@ -92,6 +92,13 @@ struct MiptScene {
   float* d_partial = nullptr;
   size_t partial_bytes = 0;
   BvhNode* d_bvh = nullptr;
+  // ray binning of the large tree batches: (cell key, ray index) pairs, sorted copy, rocPRIM's
+  // temporary storage, and the coherence probe's counter; grown on demand, kept with the scene
+  uint32_t* d_sort = nullptr;  // 4 arrays of sort_cap entries: keys, keys sorted, indices, indices sorted
+  float4* d_sorted_rays = nullptr;  // origins, directions (sort_cap each), then sort_cap limits: the batch in walking order
+  void* d_sort_tmp = nullptr;
+  unsigned int* d_breaks = nullptr;
+  size_t sort_cap = 0, sort_tmp_bytes = 0;
   int* d_big = nullptr;
   int n_tree_tris = 0;
   int n_wide_nodes = 0;
@@ -118,6 +125,10 @@ static void scene_free(MiptScene* s) {
   if (s->d_partial) (void)hipFree(s->d_partial);
   if (s->d_bvh) (void)hipFree(s->d_bvh);
   if (s->d_big) (void)hipFree(s->d_big);
+  if (s->d_sort) (void)hipFree(s->d_sort);
+  if (s->d_sorted_rays) (void)hipFree(s->d_sorted_rays);
+  if (s->d_sort_tmp) (void)hipFree(s->d_sort_tmp);
+  if (s->d_breaks) (void)hipFree(s->d_breaks);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->ev_busy) (void)hipEventDestroy(s->ev_busy);
@@ -614,6 +625,62 @@ static inline unsigned batch_grid(size_t n_rays) {
 extern "C" int mipt_scene_pair_units(MiptScene* s) { return s ? (int)s->n_pair_units : 0; }
 extern "C" int mipt_scene_axis_pair_units(MiptScene* s) { return s ? (int)s->n_axis_units : 0; }
 
+// Tree batches of SORT_MIN_RAYS rays or more: bin the rays by origin cell unless they come coherent.
+// On return b.order is null (walk the rays as they come) or b holds the batch in walking order and
+// the index each result goes to. Waits once for the coherence probe (4 bytes back to the host).
+constexpr size_t SORT_MIN_RAYS = (size_t)1 << 20;
+struct OrderedBatch {
+  const float4* origin;
+  const float4* dir;
+  const float* max_t;
+  const uint32_t* order;
+};
+static int order_rays(MiptScene* s, const float* d_origin4, const float* d_dir4, const float* d_max_t, size_t n_rays,
+                      hipStream_t st, OrderedBatch& b) {
+  b = OrderedBatch{(const float4*)d_origin4, (const float4*)d_dir4, d_max_t, nullptr};
+  if (n_rays < SORT_MIN_RAYS || n_rays > 0xFFFFFFFFull || !(s->d.scale > 0.f)) return MIPT_OK;
+  if (n_rays > s->sort_cap) {
+    if (s->busy_valid) HIP_TRY(hipEventSynchronize(s->ev_busy));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (s->d_sort) { (void)hipFree(s->d_sort); s->d_sort = nullptr; }
+    if (s->d_sorted_rays) { (void)hipFree(s->d_sorted_rays); s->d_sorted_rays = nullptr; }
+    if (s->d_sort_tmp) { (void)hipFree(s->d_sort_tmp); s->d_sort_tmp = nullptr; s->sort_tmp_bytes = 0; }
+    s->sort_cap = 0;
+    HIP_TRY(hipMalloc(&s->d_sort, n_rays * 4 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&s->d_sorted_rays, n_rays * (2 * sizeof(float4) + sizeof(float))));
+    size_t tmp = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, s->d_sort, s->d_sort + n_rays, s->d_sort + 2 * n_rays,
+                                      s->d_sort + 3 * n_rays, n_rays, 0, 12, st));
+    HIP_TRY(hipMalloc(&s->d_sort_tmp, tmp ? tmp : 1));
+    s->sort_tmp_bytes = tmp;
+    s->sort_cap = n_rays;
+    if (!s->d_breaks) HIP_TRY(hipMalloc(&s->d_breaks, sizeof(unsigned int)));
+  }
+  uint32_t* keys = s->d_sort;
+  uint32_t* keys2 = keys + s->sort_cap;
+  uint32_t* vals = keys2 + s->sort_cap;
+  uint32_t* vals2 = vals + s->sort_cap;
+  HIP_TRY(hipMemsetAsync(s->d_breaks, 0, sizeof(unsigned int), st));
+  hipLaunchKernelGGL(k_ray_cell_keys, dim3(grid_for(n_rays)), dim3(BLOCK), 0, st, (const float4*)d_origin4,
+                     (unsigned long long)n_rays, s->d.scale, keys, vals, s->d_breaks);
+  HIP_TRY(hipGetLastError());
+  unsigned int breaks = 0;
+  HIP_TRY(hipMemcpyAsync(&breaks, s->d_breaks, sizeof breaks, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  // the probe saw one workgroup in 64; fewer than one ray in eight changing cell is coherent enough
+  if ((size_t)breaks * 64 * 8 < n_rays) return MIPT_OK;
+  size_t tmp = s->sort_tmp_bytes;
+  HIP_TRY(rocprim::radix_sort_pairs(s->d_sort_tmp, tmp, keys, keys2, vals, vals2, n_rays, 0, 12, st));
+  float4* so = s->d_sorted_rays;
+  float4* sd = so + s->sort_cap;
+  float* sm = reinterpret_cast<float*>(sd + s->sort_cap);
+  hipLaunchKernelGGL(k_gather_rays, dim3(grid_for(n_rays)), dim3(BLOCK), 0, st, (const float4*)d_origin4,
+                     (const float4*)d_dir4, d_max_t, vals2, (unsigned long long)n_rays, so, sd, sm);
+  HIP_TRY(hipGetLastError());
+  b = OrderedBatch{so, sd, d_max_t ? sm : nullptr, vals2};
+  return MIPT_OK;
+}
+
 extern "C" int mipt_closest_hit_dev(MiptScene* s, const float* d_origin4, const float* d_dir4, size_t n_rays,
                                     int32_t* d_tri_idx, float* d_t, float* d_position4, void* stream) {
   if (!s) return fail(MIPT_E_INVALID, "mipt_closest_hit: scene is null");
@@ -623,12 +690,15 @@ extern "C" int mipt_closest_hit_dev(MiptScene* s, const float* d_origin4, const 
   HIP_TRY(hipSetDevice(s->device));
   if (s->d.bvh) {
     unsigned long long* q = reinterpret_cast<unsigned long long*>(s->d_queue) + 32;
-    const int rc = scratch_acquire(s, (hipStream_t)stream);
+    int rc = scratch_acquire(s, (hipStream_t)stream);
+    if (rc != MIPT_OK) return rc;
+    OrderedBatch b;
+    rc = order_rays(s, d_origin4, d_dir4, nullptr, n_rays, (hipStream_t)stream, b);
     if (rc != MIPT_OK) return rc;
     HIP_TRY(hipMemsetAsync(q, 0, BATCH_HEADS * 128, (hipStream_t)stream));
     hipLaunchKernelGGL(k_bvh_batch<false>, dim3(batch_grid(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
-                       (const float4*)d_origin4, (const float4*)d_dir4, (const float*)nullptr,
-                       (unsigned long long)n_rays, q, d_tri_idx, d_t, (float4*)d_position4, (uint8_t*)nullptr);
+                       b.origin, b.dir, (const float*)nullptr,
+                       (unsigned long long)n_rays, q, d_tri_idx, d_t, (float4*)d_position4, (uint8_t*)nullptr, b.order);
     HIP_TRY(hipGetLastError());
     return scratch_release(s, (hipStream_t)stream);
   } else
@@ -648,12 +718,15 @@ extern "C" int mipt_any_hit_dev(MiptScene* s, const float* d_origin4, const floa
   HIP_TRY(hipSetDevice(s->device));
   if (s->d.bvh) {
     unsigned long long* q = reinterpret_cast<unsigned long long*>(s->d_queue) + 32;
-    const int rc = scratch_acquire(s, (hipStream_t)stream);
+    int rc = scratch_acquire(s, (hipStream_t)stream);
+    if (rc != MIPT_OK) return rc;
+    OrderedBatch b;
+    rc = order_rays(s, d_origin4, d_dir4, d_max_t, n_rays, (hipStream_t)stream, b);
     if (rc != MIPT_OK) return rc;
     HIP_TRY(hipMemsetAsync(q, 0, BATCH_HEADS * 128, (hipStream_t)stream));
     hipLaunchKernelGGL(k_bvh_batch<true>, dim3(batch_grid(n_rays)), dim3(BLOCK), 0, (hipStream_t)stream, s->d,
-                       (const float4*)d_origin4, (const float4*)d_dir4, d_max_t, (unsigned long long)n_rays, q,
-                       (int32_t*)nullptr, (float*)nullptr, (float4*)nullptr, d_occluded);
+                       b.origin, b.dir, b.max_t, (unsigned long long)n_rays, q,
+                       (int32_t*)nullptr, (float*)nullptr, (float4*)nullptr, d_occluded, b.order);
     HIP_TRY(hipGetLastError());
     return scratch_release(s, (hipStream_t)stream);
   } else

@@ -107,9 +107,9 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_bounds(const TriRec* __restrict__
                                                       int n, Aabb* __restrict__ box, float* __restrict__ centroid,
                                                       uint32_t* __restrict__ scene) {
   const int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const int tri = subset[i];
-  const TriRec T = tris[tri];
+  const bool valid = i < n;  // lanes past the end stay for the wave-wide reduction below
+  const int tri = valid ? subset[i] : 0;
+  const TriRec T = valid ? tris[tri] : TriRec{};
   const float v0[3] = {T.v0x, T.v0y, T.v0z};
   const float e1[3] = {T.e1x, T.e1y, T.e1z}, e2[3] = {T.e2x, T.e2y, T.e2z};
   Aabb b;
@@ -123,13 +123,24 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_bounds(const TriRec* __restrict__
   }
   const float pad = 0.03f * ext + 1e-5f * mag + 1e-30f;
   for (int k = 0; k < 3; ++k) {
-    centroid[3 * i + k] = 0.5f * (b.lo[k] + b.hi[k]);
-    atomicMin(scene + k, float_flip(centroid[3 * i + k]));
-    atomicMax(scene + 3 + k, float_flip(centroid[3 * i + k]));
+    const float c = 0.5f * (b.lo[k] + b.hi[k]);
+    // scene bounds of the centroids: reduced over the wave first, one atomic pair per wave and axis
+    // (an atomic per triangle on six addresses took 1.1 ms of a 3.9 ms build of 10^6 triangles)
+    uint32_t lo = valid ? float_flip(c) : 0xFFFFFFFFu, hi = valid ? float_flip(c) : 0u;
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t lo2 = (uint32_t)__shfl_xor((int)lo, off, 64), hi2 = (uint32_t)__shfl_xor((int)hi, off, 64);
+      lo = lo2 < lo ? lo2 : lo;
+      hi = hi2 > hi ? hi2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(scene + k, lo);
+      atomicMax(scene + 3 + k, hi);
+    }
+    if (valid) centroid[3 * i + k] = c;
     b.lo[k] -= pad;
     b.hi[k] += pad;
   }
-  box[tri] = b;
+  if (valid) box[tri] = b;
 }
 
 __device__ __forceinline__ unsigned long long spread21(unsigned long long v) {  // 21 bits -> every third bit

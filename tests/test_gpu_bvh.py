@@ -426,3 +426,26 @@ def test_shipped_path_kernels_equal_counting_kernels(api, O, dtype, pkg, name):
             ref, _ = O.render_accumulate(tris, None, cam, light, p, 0, 4)
             assert (bits(img) == bits(ref)).all(axis=2).mean() > 0.99
         sc.close()
+
+
+def test_large_tree_batches_are_binned_by_origin_cell(api, O, dtype):
+    # batches of 2^20 rays or more are walked in the order of their origin cells (incoherent ones;
+    # camera rays are left as they come): every ray's result must be the one it gets in a small
+    # batch that is walked as it comes, whatever the any-hit / closest-hit kind
+    import torch
+    tris = scenes(O, dtype)["mesh140k"]
+    sc = api.Scene(tris)
+    n = 1 << 20
+    so, sd, sr = raygen.shadow_rays(tris, n, seed=31)
+    for kind, (o, d) in {"interior": raygen.interior_rays(n, seed=30), "primary": raygen.primary_rays(n, seed=32),
+                         "shadow": (so, sd)}.items():
+        o, d = _dev(o), _dev(d)
+        r = _dev(sr) if kind == "shadow" else None
+        big = _batch(sc, o, d, r)
+        q = n // 4
+        for k in range(4):
+            sl = slice(k * q, (k + 1) * q)
+            small = _batch(sc, o[sl].contiguous(), d[sl].contiguous(), None if r is None else r[sl].contiguous())
+            part = (big[0][sl], big[1][sl], big[2][sl], None if r is None else big[3][sl])
+            assert _same_hits(part, small), (kind, k)
+    sc.close()
