@@ -572,6 +572,9 @@ struct BvhTrav {
   int pend;       // a leaf met while other lanes still stepped through nodes, or BVH_DONE; cur != BVH_DONE while set
   int sp, n_list;
   float zmin, bound;
+  // closest: the nearest hit so far (smallest z) lives in registers; only hits within the tie band
+  // of it go to the list in scratch memory -- a few per cent of the rays have any
+  BvhHit best;
   bool redo;      // closest: the pruned walk cannot vouch for this ray, run bvh_closest_exhaustive
   bool hit;       // any-hit: a triangle accepted
 };
@@ -590,21 +593,23 @@ __device__ __forceinline__ void bvh_take(BvhTrav& T, BvhMem& M, const BvhRay& r,
     return;
   }
   if (!(fabsf(t - z) <= 0.000244140625f * z + r.delta)) { T.redo = true; T.cur = T.pend = BVH_DONE; }  // 2^-12
+  BvhHit extra = {i, t, z, x1, x2};  // what goes to the list, if anything (idx < 0: nothing)
   if (z < T.zmin) {
+    // a new nearest hit; the old one stays only if it is within the band of the new one
+    extra = T.best;
+    T.best = {i, t, z, x1, x2};
     T.zmin = z;
     T.bound = T.zmin * BVH_BAND + 4.0f * r.delta;
-    int w = 0;  // drop hits that fell out of the band
+    int w = 0;  // drop listed hits that fell out of the band
     for (int k = 0; k < T.n_list; ++k)
       if (M.list[k].t <= T.bound) M.list[w++] = M.list[k];
     T.n_list = w;
   }
-  if (t <= T.bound) {
+  if (extra.idx >= 0 && extra.t <= T.bound) {
     if (T.n_list == BVH_LIST) {
       T.redo = true; T.cur = T.pend = BVH_DONE;
     } else {
-      int k = T.n_list++;
-      while (k > 0 && M.list[k - 1].idx > i) { M.list[k] = M.list[k - 1]; --k; }  // keep index order
-      M.list[k] = {i, t, z, x1, x2};
+      M.list[T.n_list++] = extra;  // in no particular order; bvh_finish replays by index
     }
   }
 }
@@ -614,6 +619,7 @@ __device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, const DeviceSce
   T.cur = sc.bvh_root;
   T.pend = BVH_DONE;
   T.sp = 0; T.n_list = 0;
+  T.best = {-1, 0.f, 0.f, 0.f, 0.f};
   T.zmin = 3.402823466e+38f;
   // any-hit: t of an accepted triangle is <= max_t; its true distance can exceed that by the filter's slack
   T.bound = shadow ? fabsf(max_t) * 1.05f + 4.0f * r.delta + 1e-30f : 3.402823466e+38f;
@@ -687,13 +693,22 @@ __device__ __forceinline__ void bvh_finish(const BvhTrav& T, const BvhMem& M, bo
     return;
   }
   // the reference's sequential rule over the surviving hits, in index order (:25, :28)
-  for (int k = 0; k < T.n_list; ++k) {
-    if (M.list[k].t <= h.lim) {
-      h.set_lim(M.list[k].z);
-      h.idx = M.list[k].idx;
-      h.by = M.list[k].by;
-      h.bz = M.list[k].bz;
+  if (T.best.idx < 0) return;
+  if (T.n_list == 0) {  // the usual case: one hit, no near-tie
+    if (T.best.t <= h.lim) { h.set_lim(T.best.z); h.idx = T.best.idx; h.by = T.best.by; h.bz = T.best.bz; }
+    return;
+  }
+  int last = -1;
+  for (;;) {  // next larger index among the nearest hit and the listed ones (a triangle is met once)
+    BvhHit e = T.best;
+    bool found = e.idx > last;
+    for (int k = 0; k < T.n_list; ++k) {
+      const BvhHit c = M.list[k];
+      if (c.idx > last && (!found || c.idx < e.idx)) { e = c; found = true; }
     }
+    if (!found) break;
+    last = e.idx;
+    if (e.t <= h.lim) { h.set_lim(e.z); h.idx = e.idx; h.by = e.by; h.bz = e.bz; }
   }
 }
 

@@ -266,15 +266,17 @@ constexpr unsigned long long BATCH_RESERVE = MIPT_BATCH_RESERVE;
 #endif
 constexpr int BATCH_HEADS = MIPT_BATCH_HEADS;  // queue heads of the batch kernels, 128 bytes apart
 
-// measured best of 5..8 waves per SIMD with the vote-scheduled walk (8: spills, 6: ties on the largest scenes)
+// Waves per SIMD of the batch kernels, measured: the any-hit walk is best at 7 (8 spills); the
+// closest-hit walk carries its nearest hit in registers and is best at 6 (at 7 it spills: -15 %).
 #ifndef MIPT_BATCH_WAVES
 #define MIPT_BATCH_WAVES 7
 #endif
-#if MIPT_BATCH_WAVES
-#define MIPT_BATCH_OCC __attribute__((amdgpu_waves_per_eu(MIPT_BATCH_WAVES, MIPT_BATCH_WAVES)))
-#else
-#define MIPT_BATCH_OCC
+#ifndef MIPT_BATCH_WAVES_CLOSEST
+#define MIPT_BATCH_WAVES_CLOSEST 6
 #endif
+#define MIPT_BATCH_OCC                                                                                    \
+  __attribute__((amdgpu_waves_per_eu(SHADOW ? MIPT_BATCH_WAVES : MIPT_BATCH_WAVES_CLOSEST, \
+                                     SHADOW ? MIPT_BATCH_WAVES : MIPT_BATCH_WAVES_CLOSEST)))
 
 // Large incoherent batches walk the tree faster when rays that start in the same part of the scene
 // travel in the same wave (the top of the tree is fetched once per wave instead of once per lane:

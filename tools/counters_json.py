@@ -32,8 +32,8 @@ def main():
     fe, _ = per_kernel(f"{d}/fetch_results.db", substr)
     wr, _ = per_kernel(f"{d}/write_results.db", substr)
     l2, _ = per_kernel(f"{d}/l2_results.db", substr)
-    # average duration of the kernel in the un-instrumented stats pass (rocpd_summary prints microseconds)
-    db = sqlite3.connect(f"{d}/stats_results.db")
+    # average duration of the kernel in the SQ-counter pass itself (microseconds)
+    db = sqlite3.connect(f"{d}/sq_results.db")
     avg_us = None
     for name, avg in db.cursor().execute("select name, average from top_kernels"):
         if substr in name:
@@ -41,8 +41,12 @@ def main():
     res = {"kernel": substr, "source": f"{d}: rocprofv3 --kernel-trace --pmc passes of `bench.py --steps 3 --warmup 1 --no-cpu` "
                                        "(tools/profile_round.sh); per launch = sum over dispatches / dispatches"}
     n = lambda t: t[0] / t[1]
+    # fetch_scale=1 for kernels whose reads are 64-byte gathers (tree nodes, triangle records): their
+    # requests are 64 bytes and the counter is exact (L2 misses x 64 B agrees with it); 2 for streams
+    fetch_scale = float(extra.pop("fetch_scale", 2))
     if "FETCH_SIZE" in fe:
-        res["fetch_bytes_per_launch"] = n(fe["FETCH_SIZE"]) * 1024 * 2
+        res["fetch_bytes_per_launch"] = n(fe["FETCH_SIZE"]) * 1024 * fetch_scale
+        res["fetch_scale"] = fetch_scale
     if "WRITE_SIZE" in wr:
         res["write_bytes_per_launch"] = n(wr["WRITE_SIZE"]) * 1024
     if "fetch_bytes_per_launch" in res and "write_bytes_per_launch" in res:

@@ -33,5 +33,10 @@ python3 tools/rocpd_summary.py --only mipt:: "$OUT"/stats_results.db > "$OUT/ker
 python3 tools/rocpd_summary.py --only mipt:: "$OUT"/sq_results.db > "$OUT/pmc_sq.txt" && \
 python3 tools/rocpd_summary.py --only mipt:: "$OUT"/fetch_results.db "$OUT"/write_results.db "$OUT"/l2_results.db > "$OUT/pmc_hbm.txt" && \
 grep '^{' "$OUT/stats.log" > "$OUT/bench_line.json"
-rm -rf "$OUT"/stats "$OUT"/sq "$OUT"/fetch "$OUT"/write "$OUT"/l2
-ls -la "$OUT"
+case $WL in
+  cornell) python3 tools/counters_json.py "$OUT" "k_paths<1, false, false, 0>" "$OUT/counters_k_paths.json" size=1024 spp=1024 ;;
+  c4) python3 tools/counters_json.py "$OUT" "k_paths<1, false, false, 2>" "$OUT/counters_bvh_c4.json" fetch_scale=1 size=1024 spp=1024 ;;
+  c5) python3 tools/counters_json.py "$OUT" "k_bvh_batch<false>" "$OUT/counters_bvh_c5.json" fetch_scale=1 algorithmic_bytes_per_ray=3963 ;;
+esac > /dev/null
+rm -rf "$OUT"/stats "$OUT"/sq "$OUT"/fetch "$OUT"/write "$OUT"/l2 "$OUT"/*.db
+ls "$OUT"
