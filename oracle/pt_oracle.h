@@ -24,7 +24,9 @@
  * image level by the reference's own rendering of its glassWolf scene
  * (CW/raytracer/screenshot.bmp, kept as tests/golden/glasswolf_screen_500x500.npz):
  * this file's paths through the diffuse room reproduce that image's pixel values
- * to Monte-Carlo noise (tests/test_reference_screenshot.py). Per-path bit patterns
+ * to Monte-Carlo noise, and built with the reference's own flags (-Ofast) it also
+ * reproduces the image's glass region to noise (0.98 .. 1.00), the strict build
+ * being 1.15x brighter there (tests/test_reference_screenshot.py). Per-path bit patterns
  * have no reference vector in this image. Fog has no reference code at all:
  * "parity unpinned".
  *

@@ -102,3 +102,14 @@ def test_fog_exp_log_are_accurate(O):
         got, want = np.float32(o.or_fog_logf(float(x))), np.log(np.float64(x))
         tol = 2 * abs(np.spacing(np.float32(want))) if want != 0 else 1e-45
         assert abs(np.float64(got) - want) <= tol, (x, got, want)
+
+
+def test_oracle_runs_clean_under_the_host_sanitizers():
+    # AddressSanitizer + UndefinedBehaviorSanitizer over every entry point of the oracle (closest /
+    # any hit incl. degenerate rays, listed paths, a threaded render with fog and a sphere, tonemap)
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "sanitize"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "sanitizer run ok" in r.stdout
