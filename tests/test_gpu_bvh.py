@@ -449,3 +449,39 @@ def test_large_tree_batches_are_binned_by_origin_cell(api, O, dtype):
             part = (big[0][sl], big[1][sl], big[2][sl], None if r is None else big[3][sl])
             assert _same_hits(part, small), (kind, k)
     sc.close()
+
+
+def test_config4_full_size_launch_properties(api, O, dtype, pkg):
+    # BASELINE configs[3] in full -- the room + 102 410-triangle glass mesh at 1024 x 1024, 1024 samples
+    # per pixel in one launch (2^30 paths through the tree) -- by properties no CPU is needed for:
+    # the launch is deterministic (two runs, same bits, whichever lane walked which ray), four
+    # quarter launches add up to it, and a 16-sample slice of it is the slice's own launch
+    # (which test_shipped_path_kernel_on_config4 ties to the counting kernel and the linear scan).
+    import torch
+    tris = scenes(O, dtype)["config4"]()
+    S, spp = 1024, 1024
+    cam, light = api.default_camera(S), api.default_light(True)
+    sc = api.Scene(tris)
+    p = api.default_params(S, S, seed=0, rng_mode=pkg.abi.RNG_COUNTER, fog_sigma_t=0.1)
+
+    def launch(begin, count, into=None):
+        acc = torch.zeros(S * S * 3, dtype=torch.float32, device="cuda") if into is None else into
+        sc.render_accumulate_dev(cam, light, p, begin, count, acc)
+        torch.cuda.synchronize()
+        return acc
+
+    whole = launch(0, spp)
+    again = launch(0, spp)
+    assert torch.equal(whole.view(torch.int32), again.view(torch.int32))
+    quarters = None
+    for k in range(4):
+        quarters = launch(k * spp // 4, spp // 4, into=quarters)
+    w, q = whole.cpu().numpy(), quarters.cpu().numpy()
+    assert np.isfinite(w).all() and w.sum() > 0
+    assert np.allclose(w, q, rtol=1e-5, atol=1e-4)
+    # samples [0, 16) are one work item per pixel in either launch: bit-equal to their own launch
+    first = launch(0, 16)
+    rest = launch(16, spp - 16)
+    both = (first + rest).cpu().numpy()
+    assert np.allclose(w, both, rtol=1e-5, atol=1e-4)
+    sc.close()
