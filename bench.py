@@ -370,6 +370,10 @@ def cornell_workload(args):
                          "frac": achieved / PEAK_FP32_VECTOR, "traffic": traffic,
                          "peak_nonfused": PEAK_FP32_NONFUSED, "frac_nonfused": achieved / PEAK_FP32_NONFUSED,
                          "valu_issue_frac": hw.get("valu_issue_frac"), "active_lanes": hw.get("active_lanes"),
+                         # executed work: share of the machine's lane-operations per second that the kernel's own
+                         # VALU instructions fill (issue slots used x lanes active), no reference flops involved
+                         "executed_lane_op_frac": (hw["valu_issue_frac"] * hw["active_lanes"] / 64.0
+                                                   if hw.get("valu_issue_frac") and hw.get("active_lanes") else None),
                          "kernel": "k_paths", "kernel_ms": k_ms, "flops_per_launch": flops,
                          "tri_tests": st.tri_tests, "gate_passes": st.gate_passes,
                          "note": "achieved = algorithmic flops of the REFERENCE's scan for this launch (26 per "
