@@ -88,6 +88,14 @@ def test_argument_checks_need_no_gpu(pkg, lib):
     assert lib.mipt_closest_hit(None, None, None, 0, None, None, None) == abi.MIPT_E_INVALID
     st = abi.MiptStats()
     assert lib.mipt_get_stats(None, C.byref(st)) == abi.MIPT_E_INVALID
+    # the entry points added beside them: option bits, the call that allocates nothing, frames
+    assert lib.mipt_scene_create_opts(None, 0, None, 0, 0, 0x80, C.byref(h)) == abi.MIPT_E_INVALID
+    assert b"option bits" in lib.mipt_last_error()
+    cam, light, par = abi.MiptCamera(), abi.MiptLight(), abi.MiptParams()
+    assert lib.mipt_render_accumulate_noalloc_dev(None, C.byref(cam), C.byref(light), C.byref(par), 0, 1, None, None) == abi.MIPT_E_INVALID
+    assert lib.mipt_frame_poll(None) == abi.MIPT_E_INVALID
+    assert lib.mipt_frame_create(None, 8, 8, C.byref(h)) == abi.MIPT_E_INVALID
+    lib.mipt_frame_destroy(None)
 
 
 def test_missing_library_fails_loudly(pkg, tmp_path):
