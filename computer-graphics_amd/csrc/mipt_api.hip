@@ -98,6 +98,12 @@ struct MiptScene {
   float4* d_sorted_rays = nullptr;  // origins, directions (sort_cap each), then sort_cap limits: the batch in walking order
   void* d_sort_tmp = nullptr;
   unsigned int* d_breaks = nullptr;
+  unsigned int* h_breaks = nullptr;  // pinned: the probe's count arrives here while the batch runs
+  hipEvent_t ev_probe = nullptr;
+  bool probe_pending = false;
+  size_t probe_rays = 0;
+  int scattered = -1;   // what the last finished probe said about this scene's batches: -1 nothing yet
+  uint32_t calls_since_probe = 0;
   size_t sort_cap = 0, sort_tmp_bytes = 0;
   int* d_big = nullptr;
   int n_tree_tris = 0;
@@ -129,6 +135,8 @@ static void scene_free(MiptScene* s) {
   if (s->d_sorted_rays) (void)hipFree(s->d_sorted_rays);
   if (s->d_sort_tmp) (void)hipFree(s->d_sort_tmp);
   if (s->d_breaks) (void)hipFree(s->d_breaks);
+  if (s->h_breaks) (void)hipHostFree(s->h_breaks);
+  if (s->ev_probe) (void)hipEventDestroy(s->ev_probe);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->ev_busy) (void)hipEventDestroy(s->ev_busy);
@@ -627,7 +635,10 @@ extern "C" int mipt_scene_axis_pair_units(MiptScene* s) { return s ? (int)s->n_a
 
 // Tree batches of SORT_MIN_RAYS rays or more: bin the rays by origin cell unless they come coherent.
 // On return b.order is null (walk the rays as they come) or b holds the batch in walking order and
-// the index each result goes to. Waits once for the coherence probe (4 bytes back to the host).
+// the index each result goes to. Whether a scene's batches come scattered is learnt without waiting:
+// every such call may launch a probe whose count travels to pinned host memory while the batch runs,
+// and the NEXT call reads it (batches of one caller resemble each other; the order only affects
+// speed, never results). The first big batch of a scene is therefore walked as it comes.
 constexpr size_t SORT_MIN_RAYS = (size_t)1 << 20;
 struct OrderedBatch {
   const float4* origin;
@@ -655,20 +666,35 @@ static int order_rays(MiptScene* s, const float* d_origin4, const float* d_dir4,
     s->sort_tmp_bytes = tmp;
     s->sort_cap = n_rays;
     if (!s->d_breaks) HIP_TRY(hipMalloc(&s->d_breaks, sizeof(unsigned int)));
+    if (!s->h_breaks) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_breaks), sizeof(unsigned int), hipHostMallocDefault));
+    if (!s->ev_probe) HIP_TRY(hipEventCreateWithFlags(&s->ev_probe, hipEventDisableTiming));
   }
   uint32_t* keys = s->d_sort;
   uint32_t* keys2 = keys + s->sort_cap;
   uint32_t* vals = keys2 + s->sort_cap;
   uint32_t* vals2 = vals + s->sort_cap;
-  HIP_TRY(hipMemsetAsync(s->d_breaks, 0, sizeof(unsigned int), st));
+  if (s->probe_pending && hipEventQuery(s->ev_probe) == hipSuccess) {
+    // the probe saw one workgroup in 64; fewer than one ray in eight changing cell is coherent enough
+    s->scattered = (size_t)*s->h_breaks * 64 * 8 >= s->probe_rays ? 1 : 0;
+    s->probe_pending = false;
+    s->calls_since_probe = 0;
+  }
+  (void)hipGetLastError();  // hipErrorNotReady from the query is not an error
+  // keys are needed when sorting, and for a fresh probe: always while nothing is known, else now and then
+  const bool sort = s->scattered == 1;
+  const bool probe = !s->probe_pending && (s->scattered < 0 || sort || (++s->calls_since_probe & 15u) == 0);
+  if (!sort && !probe) return MIPT_OK;
+  if (probe) HIP_TRY(hipMemsetAsync(s->d_breaks, 0, sizeof(unsigned int), st));
   hipLaunchKernelGGL(k_ray_cell_keys, dim3(grid_for(n_rays)), dim3(BLOCK), 0, st, (const float4*)d_origin4,
-                     (unsigned long long)n_rays, s->d.scale, keys, vals, s->d_breaks);
+                     (unsigned long long)n_rays, s->d.scale, keys, vals, probe ? s->d_breaks : nullptr);
   HIP_TRY(hipGetLastError());
-  unsigned int breaks = 0;
-  HIP_TRY(hipMemcpyAsync(&breaks, s->d_breaks, sizeof breaks, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  // the probe saw one workgroup in 64; fewer than one ray in eight changing cell is coherent enough
-  if ((size_t)breaks * 64 * 8 < n_rays) return MIPT_OK;
+  if (probe) {
+    HIP_TRY(hipMemcpyAsync(s->h_breaks, s->d_breaks, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(s->ev_probe, st));
+    s->probe_pending = true;
+    s->probe_rays = n_rays;
+  }
+  if (!sort) return MIPT_OK;
   size_t tmp = s->sort_tmp_bytes;
   HIP_TRY(rocprim::radix_sort_pairs(s->d_sort_tmp, tmp, keys, keys2, vals, vals2, n_rays, 0, 12, st));
   float4* so = s->d_sorted_rays;

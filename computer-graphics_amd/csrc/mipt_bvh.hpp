@@ -552,10 +552,12 @@ __device__ __forceinline__ BvhRay bvh_ray(const DeviceScene& sc, V4 o, V4 d) {
 }
 
 // could the reference accept this triangle at all? intersections.cpp:25 with min = FLT_MAX, :27
+// FILTER = false: the caller has run the candidate filter on this triangle already (scan units)
+template <bool FILTER = true>
 __device__ __forceinline__ bool bvh_leaf(const DeviceScene& sc, const BvhRay& r, int i, float& t, float& z,
                                          float& x1, float& x2) {
   const TriRec T = sc.tris[i];
-  if (!tri_candidate(&T, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.Dm)) return false;
+  if (FILTER && !tri_candidate(&T, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.Dm)) return false;
   float x0;
   tri_eval(&T, r.o.x, r.o.y, r.o.z, r.px, r.py, r.pz, t, x0, x1, x2);
   z = fabsf(x0);
@@ -635,7 +637,7 @@ __device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, const DeviceSce
       const int i = sc.big_ids[base + __ffs((int)mask) - 1];
       mask &= mask - 1u;
       float t, z, x1, x2;
-      if (bvh_leaf(sc, r, i, t, z, x1, x2)) bvh_take(T, M, r, shadow, max_t, i, t, z, x1, x2);
+      if (bvh_leaf<false>(sc, r, i, t, z, x1, x2)) bvh_take(T, M, r, shadow, max_t, i, t, z, x1, x2);
     }
   }
   // a big triangle may have ended the query (any-hit found, or redo) before the tree had a say

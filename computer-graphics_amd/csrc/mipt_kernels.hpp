@@ -305,9 +305,9 @@ __global__ __launch_bounds__(BLOCK) void k_ray_cell_keys(const float4* __restric
     keys[i] = key;
     vals[i] = (uint32_t)i;
   }
-  // the probe looks at one workgroup in 64 (an atomic per wave of the whole batch would cost more
-  // than the sort)
-  if ((blockIdx.x & 63u) != 0u) return;
+  // the probe (when asked for) looks at one workgroup in 64 (an atomic per wave of the whole batch
+  // would cost more than the sort)
+  if (!n_breaks || (blockIdx.x & 63u) != 0u) return;
   const uint32_t prev = (uint32_t)__shfl_up((int)key, 1, 64);
   const bool brk = i < n_rays && (threadIdx.x & 63) != 0 && prev != key;
   const unsigned long long b = __ballot(brk);

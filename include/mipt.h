@@ -252,10 +252,10 @@ int mipt_trace_paths(MiptScene* scene, const MiptCamera* cam, const MiptLight* l
 
 /* Device-pointer variants: every buffer already lives in the memory of the scene's
  * GPU, `stream` is a hipStream_t (NULL = default stream). Launch is asynchronous;
- * the caller synchronises the stream. (One exception: a batch of 2^20 rays or more
- * against a tree scene is first probed for coherence -- the call waits for 4 bytes
- * from the device -- and, if its origins are scattered, walked in the order of their
- * cells on a 16^3 grid; results land at the rays' own indices either way.) Used by the one-process-per-GPU driver so
+ * the caller synchronises the stream. (Batches of 2^20 rays or more against a tree
+ * scene are probed for coherence in passing; once a scene's batches have shown
+ * scattered origins, later ones are walked in the order of their origins' cells on a
+ * 16^3 grid. Results land at the rays' own indices and do not depend on it.) Used by the one-process-per-GPU driver so
  * that the accumulation buffer can be handed to RCCL without a host round trip. */
 int mipt_closest_hit_dev(MiptScene* scene, const float* d_origin4, const float* d_dir4,
                          size_t n_rays, int32_t* d_tri_idx, float* d_t, float* d_position4,

@@ -429,9 +429,10 @@ def test_shipped_path_kernels_equal_counting_kernels(api, O, dtype, pkg, name):
 
 
 def test_large_tree_batches_are_binned_by_origin_cell(api, O, dtype):
-    # batches of 2^20 rays or more are walked in the order of their origin cells (incoherent ones;
-    # camera rays are left as they come): every ray's result must be the one it gets in a small
-    # batch that is walked as it comes, whatever the any-hit / closest-hit kind
+    # batches of 2^20 rays or more are walked in the order of their origin cells once a probe has
+    # found a scene's batches scattered (the probe of one call steers the next): every ray's result
+    # must be the one it gets in a small batch that is walked as it comes, whatever the kind of batch
+    # and whatever the previous batch looked like
     import torch
     tris = scenes(O, dtype)["mesh140k"]
     sc = api.Scene(tris)
@@ -441,7 +442,10 @@ def test_large_tree_batches_are_binned_by_origin_cell(api, O, dtype):
                          "shadow": (so, sd)}.items():
         o, d = _dev(o), _dev(d)
         r = _dev(sr) if kind == "shadow" else None
+        # twice: what the first batch's probe found decides how the second one is walked
+        first = _batch(sc, o, d, r)
         big = _batch(sc, o, d, r)
+        assert _same_hits(first, big), kind
         q = n // 4
         for k in range(4):
             sl = slice(k * q, (k + 1) * q)
