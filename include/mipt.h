@@ -275,7 +275,7 @@ int mipt_resolve_argb_dev(MiptScene* scene, const float* d_accum_rgb, int width,
  * scene's growable scratch, and the call makes no hipMalloc / hipFree / event call: one memset, the
  * path kernel and the ordered sum, all on `stream`.
  *   Limit: width * height * 12 bytes * ceil(sample_count / 16) <= MIPT_NOALLOC_MAX_BYTES
- *   (1024 x 1024 at up to 32 samples per call, 512 x 512 at up to 128); larger calls return
+ *   (1024 x 1024 at up to 32 samples per call, 512 x 512 at up to 160); larger calls return
  *   MIPT_E_INVALID -- split the sample range over several calls, ranges compose exactly.
  *   The array is shared by every scene and stream on a GPU (each GPU has its own copy, resident
  *   until the process ends): two such calls that overlap on one GPU race; issue them on one stream
