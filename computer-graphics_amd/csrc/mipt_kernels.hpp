@@ -72,11 +72,12 @@ enum ProfSection {
 };
 #ifdef MIPT_PROFILE_SECTIONS
 struct Prof {
-  uint32_t last;
+  uint32_t last;  // wave-uniform (kept in a scalar register): the time of the last mark the WAVE passed,
+                  // whichever of its lanes were active there
   uint32_t* lds;
-  __device__ __forceinline__ void start() { last = (uint32_t)__builtin_readcyclecounter(); }
+  __device__ __forceinline__ void start() { last = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_readcyclecounter()); }
   __device__ __forceinline__ void mark(int k) {
-    const uint32_t now = (uint32_t)__builtin_readcyclecounter();
+    const uint32_t now = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_readcyclecounter());
     if (lds && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(lds + k, now - last);
     last = now;
   }
@@ -84,6 +85,15 @@ struct Prof {
   __device__ __forceinline__ void count_wave(int k) {
     if (lds && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(lds + k, 1u);
   }
+};
+#elif defined(MIPT_ASM_SECTIONS)
+// Developer build: the section boundaries as comments in the ISA listing (`make asm EXTRA=-DMIPT_ASM_SECTIONS`)
+struct Prof {
+  uint32_t* lds;
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void mark(int k) { asm volatile("; ==SEC %0" ::"i"(k) : "memory"); }
+  __device__ __forceinline__ void count(int, uint32_t) {}
+  __device__ __forceinline__ void count_wave(int) {}
 };
 #else
 struct Prof {
