@@ -161,14 +161,21 @@ def load_counters(name):
         return None
 
 
-def init_ranks(backend="nccl"):
+def init_ranks(rehearse=False):
+    """rehearse: every rank on GPU 0 and gloo for the collectives (RCCL refuses two ranks on one device):
+    the N-rank code path on a one-GPU machine, for checking it -- the timings mean nothing."""
     import torch
     import torch.distributed as dist
     world, rank, local_rank = rank_env()
+    if rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -179,7 +186,7 @@ def init_ranks(backend="nccl"):
 
     def max_over_ranks(dt):
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         return dt
@@ -202,7 +209,7 @@ def tree_workload(args):
     import bigscenes
     import raygen
 
-    world, rank, dev, barrier, max_over_ranks = init_ranks()
+    world, rank, dev, barrier, max_over_ranks = init_ranks(args.rehearse)
     pkg = graft.load_package()
     abi, api = pkg.abi, pkg.api
     from computer_graphics_amd import parallel
@@ -222,7 +229,8 @@ def tree_workload(args):
             scene.render_accumulate_dev(cam, light, params, begin, count, image)
 
         def step(k):
-            parallel.render_distributed(render, k * global_spp, global_spp, rank, world, buf, total)
+            parallel.render_distributed(render, k * global_spp, global_spp, rank, world, buf, total,
+                                        via_host=args.rehearse)
         units_per_step, unit = SIZE * SIZE * global_spp, "paths/s"
         label = (f"empty Cornell room + 102 400-triangle glass mesh (LBVH), {SIZE}x{SIZE}, {global_spp} spp per step"
                  f"{' split over the GPUs' if world > 1 else ''}, fog on; stand-in for BASELINE configs[3]")
@@ -250,6 +258,8 @@ def tree_workload(args):
                 "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                 "scaling": args.scaling if args.workload == "c4" else "strong", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic", "config": {"workload": label, "parallelism": f"x{world}"}}
+        if args.rehearse:
+            line["rehearsal"] = "all ranks on one GPU, gloo through the host: not a measurement"
         hw = load_counters(f"counters_bvh_{args.workload}.json")
         if args.workload == "c4":
             sp = abi.MiptParams.from_buffer_copy(bytes(params))
@@ -284,7 +294,7 @@ def tree_workload(args):
 def cornell_workload(args):
     import torch
 
-    world, rank, dev, barrier, max_over_ranks = init_ranks()
+    world, rank, dev, barrier, max_over_ranks = init_ranks(args.rehearse)
     pkg = graft.load_package()
     abi, api = pkg.abi, pkg.api
     from computer_graphics_amd import parallel
@@ -314,7 +324,8 @@ def cornell_workload(args):
 
     def one_step(k):
         # the step's global sample range is split into `world` contiguous sub-ranges; one sum-reduce
-        parallel.render_distributed(render, k * global_spp, global_spp, rank, world, step_buf, total)
+        parallel.render_distributed(render, k * global_spp, global_spp, rank, world, step_buf, total,
+                                        via_host=args.rehearse)
         if k >= args.warmup and rank == 0:
             kernel_ms.append(scene.stats().kernel_ms)  # HIP events around the path kernel on its launch stream
 
@@ -388,9 +399,13 @@ def cornell_workload(args):
                                  "HBM bytes per launch (12 bytes written per 16-sample work item; the 22 triangles "
                                  "stay in the scalar cache and LDS)"},
         }
+        if args.rehearse:
+            line["rehearsal"] = "all ranks on one GPU, gloo through the host: not a measurement"
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(abi, tris, light, params)
         print(json.dumps(line), flush=True)
+        if args.save_total:
+            np.save(args.save_total, total.cpu().numpy())
 
     scene.close()
     finish_ranks(world)
@@ -407,6 +422,11 @@ def main():
     ap.add_argument("--spp", type=int, default=0,
                     help="override: samples per pixel per step (strong: in total; weak: per GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on a one-GPU machine: all ranks on GPU 0, gloo instead of RCCL, images reduced through "
+                         "the host. Checks the N-rank code path; the line says so and its timings mean nothing")
+    ap.add_argument("--save-total", default=None, metavar="FILE.npy",
+                    help="cornell: rank 0 saves the image summed over all warm-up and timed steps (for checks)")
     ap.add_argument("--workload", choices=["cornell", "c4", "c5"], default="cornell",
                     help="cornell = BASELINE configs[1]/[2] (the bench line the driver records); c4 / c5 = the "
                          "tree-scene stand-ins for configs[3] / configs[4] (extra lines, same JSON shape)")

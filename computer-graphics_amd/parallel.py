@@ -20,16 +20,25 @@ def rank_sample_range(sample_begin, sample_count, rank, world):
     return begin, base + (1 if rank < extra else 0)
 
 
-def reduce_image(rank_image, total, rank, world, group=None):
-    """Sum the per-rank images into rank 0's running image `total` (None on other ranks)."""
+def reduce_image(rank_image, total, rank, world, group=None, via_host=False):
+    """Sum the per-rank images into rank 0's running image `total` (None on other ranks).
+    via_host: the backend cannot reduce device tensors (gloo with images in HBM): the image makes
+    the round trip through host memory."""
     if world > 1:
         import torch.distributed as dist
-        dist.reduce(rank_image, dst=0, op=dist.ReduceOp.SUM, group=group)
+        if via_host and rank_image.is_cuda:
+            staged = rank_image.cpu()
+            dist.reduce(staged, dst=0, op=dist.ReduceOp.SUM, group=group)
+            if rank == 0:
+                rank_image.copy_(staged)
+        else:
+            dist.reduce(rank_image, dst=0, op=dist.ReduceOp.SUM, group=group)
     if rank == 0:
         total += rank_image
 
 
-def render_distributed(render_fn, sample_begin, sample_count, rank, world, rank_image, total, group=None):
+def render_distributed(render_fn, sample_begin, sample_count, rank, world, rank_image, total, group=None,
+                       via_host=False):
     """render_fn(begin, count, image) must ADD samples [begin, begin+count) of every pixel into
     `image` (Scene.render_accumulate_dev, or any renderer with the same contract). After the
     call rank 0's `total` has gained the whole range [sample_begin, sample_begin+sample_count)."""
@@ -37,4 +46,4 @@ def render_distributed(render_fn, sample_begin, sample_count, rank, world, rank_
     rank_image.zero_()
     if count:
         render_fn(begin, count, rank_image)
-    reduce_image(rank_image, total, rank, world, group)
+    reduce_image(rank_image, total, rank, world, group, via_host)

@@ -63,3 +63,46 @@ def test_one_device_through_rccl_equals_the_plain_scene(pkg, O):
     with pytest.raises(api.MiptError) as e:
         api.MultiScene(tris, None, devices=(0, 99))
     assert e.value.code in (abi.MIPT_E_INVALID, abi.MIPT_E_HIP, abi.MIPT_E_RCCL)
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_rehearsed_on_one_gpu(pkg, tmp_path):
+    # `python bench.py --gpus 2` as the driver starts it (the script becomes the launcher of two rank
+    # processes), with both ranks on GPU 0 and gloo in place of RCCL: sample split, per-rank launches,
+    # reduce to rank 0, one JSON line from rank 0. The summed image equals one scene's rendering of
+    # the same samples.
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    import bench
+    api, abi = pkg.api, pkg.abi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "total.npy")
+    spp, steps, warmup = 6, 1, 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse", "--steps", str(steps),
+                        "--warmup", str(warmup), "--spp", str(spp), "--no-cpu", "--save-total", out],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and "rehearsal" in line
+    assert line["config"]["spp_per_gpu_per_step"] == spp // 2 and line["config"]["global_spp_per_step"] == spp
+    got = np.load(out)
+    S = bench.SIZE
+    tris = api.load_test_model(abi.SCENE_GLASS_CUBE)
+    cam, light = api.default_camera(S), api.default_light(glass=True)
+    p = api.default_params(S, S, rng_mode=abi.RNG_COUNTER, seed=0, fog_sigma_t=bench.FOG_SIGMA_T,
+                           fog_albedo=bench.FOG_ALBEDO)
+    sc = api.Scene(tris)
+    acc = torch.zeros(S * S * 3, dtype=torch.float32, device="cuda")
+    sc.render_accumulate_dev(cam, light, p, 0, spp * (steps + warmup), acc)
+    torch.cuda.synchronize()
+    want = acc.cpu().numpy()
+    sc.close()
+    assert want.sum() > 0
+    # the same samples, added in another order (per rank, then per step)
+    assert np.allclose(got, want, rtol=2e-5, atol=1e-6)
