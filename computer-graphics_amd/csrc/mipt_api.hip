@@ -273,8 +273,17 @@ static int upload_scan_units(MiptScene* s, const std::vector<ScanUnit>& units);
 static int build_tree_scene(MiptScene* s, const MiptTriangle* tris, const std::vector<TriRec>& tr, size_t n_tris) {
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   std::vector<float> extent(n_tris);
+  // A triangle with a NaN, infinite or enormous coordinate (beyond 2^40, where the filters' error
+  // bounds stop holding) must not shape the tree: its box would poison every node above it. Such
+  // triangles are tested one by one like the big ones -- the filter passes them unexamined and the
+  // reference's own arithmetic decides -- and the scene's extent is taken over the others.
+  std::vector<char> odd(n_tris, 0);
   for (size_t i = 0; i < n_tris; ++i) {
     const float* v[3] = {tris[i].v0, tris[i].v1, tris[i].v2};
+    for (int j = 0; j < 3; ++j)
+      for (int k = 0; k < 3; ++k)
+        if (!(std::fabs(v[j][k]) <= 1.0995116e12f)) odd[i] = 1;
+    if (odd[i]) continue;
     float e = 0.f;
     for (int k = 0; k < 3; ++k) {
       const float a = std::fmin(v[0][k], std::fmin(v[1][k], v[2][k])), b = std::fmax(v[0][k], std::fmax(v[1][k], v[2][k]));
@@ -282,11 +291,14 @@ static int build_tree_scene(MiptScene* s, const MiptTriangle* tris, const std::v
       if (b > hi[k]) hi[k] = b;
       e = std::fmax(e, b - a);
     }
-    extent[i] = e;  // NaN vertices give NaN or 0 here: never "big", they stay in the tree
+    extent[i] = e;
   }
   const float scene_extent = std::fmax(hi[0] - lo[0], std::fmax(hi[1] - lo[1], hi[2] - lo[2]));
-  std::vector<int> big, small;
-  for (size_t i = 0; i < n_tris; ++i) (extent[i] > 0.125f * scene_extent ? big : small).push_back((int)i);
+  std::vector<int> big, small, odd_ids;
+  for (size_t i = 0; i < n_tris; ++i) {
+    if (odd[i]) odd_ids.push_back((int)i);
+    else (extent[i] > 0.125f * scene_extent ? big : small).push_back((int)i);
+  }
   if (big.size() > MAX_BIG) {  // keep the largest, in index order; the rest go into the tree after all
     std::vector<int> by_size = big;
     std::sort(by_size.begin(), by_size.end(), [&](int a, int b) { return extent[a] > extent[b] || (extent[a] == extent[b] && a < b); });
@@ -297,6 +309,10 @@ static int build_tree_scene(MiptScene* s, const MiptTriangle* tris, const std::v
     small.insert(small.end(), rest.begin(), rest.end());
     std::sort(small.begin(), small.end());
     big = by_size;
+  }
+  if (!odd_ids.empty()) {  // however many there are
+    big.insert(big.end(), odd_ids.begin(), odd_ids.end());
+    std::sort(big.begin(), big.end());
   }
 #ifdef MIPT_DEV_SWITCHES
   const char* no_big = getenv("MIPT_NO_BIG_LIST");  // developer build only: every triangle in the tree

@@ -489,3 +489,50 @@ def test_config4_full_size_launch_properties(api, O, dtype, pkg):
     both = (first + rest).cpu().numpy()
     assert np.allclose(w, both, rtol=1e-5, atol=1e-4)
     sc.close()
+
+
+@pytest.mark.parametrize("case", ["nan", "inf", "huge", "flat", "all"])
+def test_odd_triangles_in_a_tree_scene(api, O, dtype, case):
+    # triangles no mesh should hold but files do: NaN / infinite / enormous vertices, zero area. The
+    # reference's scan never accepts most of them and is unimpressed by the rest; they must not
+    # shape the tree, and every ray gets the linear scan's answer
+    tris = bigscenes.mesh_in_room(O, dtype, cells=24, nu=32, nv=16).copy()
+    assert len(tris) >= 256
+    k = [40, 300, 700, 1100, 1500, 1900]
+    if case in ("nan", "all"):
+        tris["v1"][k[0], :3] = np.nan
+        tris["v0"][k[1], 1] = np.nan
+    if case in ("inf", "all"):
+        tris["v2"][k[2], 0] = np.inf
+        tris["v0"][k[3], :3] = -np.inf
+    if case in ("huge", "all"):
+        tris["v1"][k[4], :3] = [1e30, -1e30, 1e30]
+        tris["v0"][k[5], :3] = 3e38
+        tris["v1"][k[5], :3] = -3e38
+    if case in ("flat", "all"):
+        tris["v1"][k[0] + 1] = tris["v0"][k[0] + 1]
+        tris["v2"][k[0] + 1] = tris["v0"][k[0] + 1]
+        tris["v2"][k[1] + 1] = tris["v1"][k[1] + 1]
+    tree = api.Scene(tris)
+    flat = api.Scene(tris, linear_scan=True)
+    assert tree.bvh_info()[0] and not flat.bvh_info()[0]
+    n = 1 << 15
+    for kind, (o, d) in {"primary": raygen.primary_rays(n), "interior": raygen.interior_rays(n),
+                         "degenerate": raygen.degenerate_rays(tris[:64], 4096)}.items():
+        i1, t1, p1 = tree.closest_hit(o, d)
+        i2, t2, p2 = flat.closest_hit(o, d)
+        assert np.array_equal(i1, i2), (case, kind, np.count_nonzero(i1 != i2))
+        hit = i2 >= 0
+        assert hit.mean() > (0.8 if kind != "degenerate" else 0.05)
+        assert np.array_equal(bits(t1[hit]), bits(t2[hit])) and np.array_equal(bits(p1[hit]), bits(p2[hit]))
+    o, d, r = raygen.shadow_rays(tris, n)
+    assert np.array_equal(tree.any_hit(o, d, r), flat.any_hit(o, d, r))
+    # whole paths: the shipped tree kernel against the same triangles scanned linearly
+    W = 64
+    cam, light = O.default_camera(W), O.default_light(True)
+    p = O.default_params(W, W, seed=5, rng_mode=1)  # counter RNG
+    a = tree.render_accumulate(cam, light, p, 0, 4)
+    b = flat.render_accumulate(cam, light, p, 0, 4)
+    assert a.sum() > 0 and np.mean(bits(a) == bits(b)) > 0.99
+    tree.close()
+    flat.close()
