@@ -536,3 +536,36 @@ def test_odd_triangles_in_a_tree_scene(api, O, dtype, case):
     assert a.sum() > 0 and np.mean(bits(a) == bits(b)) > 0.99
     tree.close()
     flat.close()
+
+
+def test_odd_rays_and_odd_triangles_against_the_oracle(api, O, dtype):
+    # NaN / infinite / enormous ray components, against a tree scene and a linear-scan scene that both
+    # hold odd triangles; the CPU oracle is the judge
+    rng = np.random.default_rng(11)
+    big = bigscenes.mesh_in_room(O, dtype, cells=24, nu=32, nv=16).copy()
+    small = np.concatenate([bigscenes.room(O), bigscenes.soup(dtype, 150, seed=12, size=0.2)])
+    for tris in (big, small):
+        m = len(tris)
+        tris["v1"][m // 7, :3] = np.nan
+        tris["v2"][m // 5, 2] = np.inf
+        tris["v0"][m // 3, :3] = [2e12, 0, -3e20]
+        tris["v1"][m // 2] = tris["v0"][m // 2]
+    n = 6000
+    o, d = raygen.interior_rays(n, seed=13)
+    odd = [np.nan, np.inf, -np.inf, 1e25, -3e38, 0.0, 1e-42]
+    for i in range(0, n, 3):  # a third of the rays get one odd component
+        (o if i % 2 else d)[i, rng.integers(0, 3)] = odd[(i // 3) % len(odd)]
+    lim = rng.uniform(0.1, 3.0, n).astype(np.float32)
+    lim[::50] = np.inf
+    lim[7::50] = np.nan
+    for tris, tree in ((big, True), (small, False)):
+        sc = api.Scene(tris)
+        assert sc.bvh_info()[0] == tree
+        idx, t, pos = sc.closest_hit(o, d)
+        oidx, ot, opos = O.closest_hit(tris, None, o, d)
+        assert np.array_equal(idx, oidx), (tree, np.count_nonzero(idx != oidx))
+        hit = oidx >= 0
+        assert hit.sum() > n // 2
+        assert np.array_equal(bits(t[hit]), bits(ot[hit])) and np.array_equal(bits(pos[hit]), bits(opos[hit]))
+        assert np.array_equal(sc.any_hit(o, d, lim), O.any_hit(tris, o, d, lim))
+        sc.close()
