@@ -1304,14 +1304,18 @@ extern "C" int mipt_debug_selfcheck(MiptScene* s, uint64_t n_rays, uint32_t seed
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_selfcheck_sincos, dim3(4096), dim3(BLOCK), 0, nullptr, d.as<unsigned long long>());
   HIP_TRY(hipGetLastError());
-  if (n_rays) {
-    const dim3 grid((unsigned)((n_rays + BLOCK - 1) / BLOCK));
+  // a launch holds fewer than 2^32 threads: 2^30 rays per launch, each with a seed of its own
+  const uint64_t per_launch = (uint64_t)1 << 30;
+  uint32_t launch_seed = seed;
+  for (uint64_t done = 0; done < n_rays; done += per_launch, launch_seed += 0x9E3779B9u) {
+    const uint64_t n = n_rays - done < per_launch ? n_rays - done : per_launch;
+    const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
     if (s->d.bvh)
-      hipLaunchKernelGGL(k_selfcheck_scan<true>, grid, dim3(BLOCK), 0, nullptr, s->d, (unsigned long long)n_rays,
-                         seed, d.as<unsigned long long>());
+      hipLaunchKernelGGL(k_selfcheck_scan<true>, grid, dim3(BLOCK), 0, nullptr, s->d, (unsigned long long)n,
+                         launch_seed, d.as<unsigned long long>());
     else
-      hipLaunchKernelGGL(k_selfcheck_scan<false>, grid, dim3(BLOCK), 0, nullptr, s->d, (unsigned long long)n_rays,
-                         seed, d.as<unsigned long long>());
+      hipLaunchKernelGGL(k_selfcheck_scan<false>, grid, dim3(BLOCK), 0, nullptr, s->d, (unsigned long long)n,
+                         launch_seed, d.as<unsigned long long>());
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipDeviceSynchronize());

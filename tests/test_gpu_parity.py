@@ -70,6 +70,14 @@ def test_fast_scan_equals_literal_scan_at_scale(api, O, scene):
     assert closest_bad == 0 and any_bad == 0, (closest_bad, any_bad)
 
 
+def test_selfcheck_beyond_one_launch(api, O):
+    # more rays than one launch holds threads: split into launches of 2^30, a seed each
+    sc = api.Scene(O.load_test_model(2))
+    _, _, closest_bad, any_bad = sc.selfcheck((1 << 32) + 12345, seed=5)
+    sc.close()
+    assert (closest_bad, any_bad) == (0, 0)
+
+
 def test_closest_hit_with_sphere(api, O):
     tris = O.load_test_model(2)
     sph = api.make_sphere(0.3, [-0.45, 0.7, -0.55, 1], [1, 0, 0])  # main.cpp:75
