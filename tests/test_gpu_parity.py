@@ -193,6 +193,32 @@ def test_render_accumulate_matches_oracle(api, O, pkg, scene, W, H):
         assert abs(a - b) <= (0 if scene == "cornell" else 1e-3 * b), (k, a, b)
 
 
+def test_config0_whole_frame_is_the_oracle_frame(api, O, pkg):
+    # BASELINE configs[0] in full: the Cornell test model at 256 x 256, 16 spp, diffuse only, no fog,
+    # the reference's random engine seeded per path. 16 samples are one work item: one lane adds a
+    # pixel's radiances in sample order exactly like main.cpp:137 does, so the frames agree bit for
+    # bit -- accumulation buffer, ARGB screen and every counter
+    abi = pkg.abi
+    W = H = 256
+    tris = O.load_test_model(0)
+    cam, light = O.default_camera(W), O.default_light(False)
+    for flags in (0, abi.FLAG_STATS):   # the shipped kernel and the counting one
+        p = O.default_params(W, H, seed=0, rng_mode=abi.RNG_MINSTD_PATH, flags=flags)
+        sc = api.Scene(tris)
+        acc = sc.render_accumulate(cam, light, p, 0, 16)
+        st = sc.stats()
+        argb = sc.resolve_argb(acc, 16)
+        sc.close()
+        oacc, ost = O.render_accumulate(tris, None, cam, light, p, 0, 16)
+        assert oacc.sum() > 0
+        assert np.array_equal(bits(acc), bits(oacc)), np.count_nonzero(bits(acc) != bits(oacc))
+        assert np.array_equal(argb, O.resolve_argb(oacc, 16))
+        if flags:
+            for k in ("paths", "closest_rays", "shadow_rays", "tri_tests", "gate_passes", "diffuse_bounces"):
+                assert getattr(st, k) == getattr(ost, k), k
+            assert st.mirror_bounces == st.glass_bounces == 0
+
+
 def test_render_sample_ranges_compose(api, O):
     # samples [0,64) in one call == [0,32) then [32,64) accumulated: the stream of a path
     # depends only on (pixel, sample index), and chunk images are added in order
