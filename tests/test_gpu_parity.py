@@ -5,6 +5,8 @@ bit-pattern work); per-path radiance compared bit for bit too, with the fraction
 allowed to differ stated per test (the only device/host difference is powf in the Fresnel
 comparison of glass vertices; cosf/sinf reproduce glibc's results).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -245,6 +247,27 @@ def test_bench_workload_image_is_the_oracle_image(api, O, pkg, rng):
         acc = sc.render_accumulate(cam, light, p, 0, spp)
         sc.close()
         assert np.array_equal(bits(acc), bits(want)), (flags, np.count_nonzero(bits(acc) != bits(want)))
+
+
+def test_bench_frame_at_full_resolution_is_the_oracle_frame(api, O, pkg):
+    # BASELINE configs[1] at its 1024 x 1024 with a quarter of its samples (2.7 * 10^8 paths; the CPU side
+    # takes ~20 s on 16 threads). All 1024 samples were compared once with tools/full_frame_parity.py:
+    # 0 of 3 145 728 channel sums differ (profiles/r2_full_frame_parity.json).
+    import bench
+    abi = pkg.abi
+    S, spp = bench.SIZE, 256
+    threads = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "0") or 64))
+    tris = O.load_test_model(2)
+    cam, light = O.default_camera(S), O.default_light(True)
+    p = O.default_params(S, S, seed=0, rng_mode=abi.RNG_COUNTER, fog_sigma_t=bench.FOG_SIGMA_T, fog_albedo=bench.FOG_ALBEDO)
+    sc = api.Scene(tris)
+    acc = sc.render_accumulate(cam, light, p, 0, spp)
+    sc.close()
+    want = None
+    for b in range(0, spp, 16):
+        img, _ = O.render_accumulate(tris, None, cam, light, p, b, 16, threads=threads)
+        want = img.copy() if want is None else (want + img).astype(np.float32)
+    assert want.sum() > 0 and np.array_equal(bits(acc), bits(want)), np.count_nonzero(bits(acc) != bits(want))
 
 
 def test_render_sample_ranges_compose(api, O):
