@@ -26,15 +26,20 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--size", type=int, default=bench.SIZE)
     ap.add_argument("--threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "8")))
+    ap.add_argument("--scene", type=int, default=2, help="test model: 0 Cornell, 1 glass cube + room for the sphere, 2 GlassCube (bench), 3 empty room")
+    ap.add_argument("--rng", choices=["counter", "minstd"], default="counter")
+    ap.add_argument("--fog", type=float, default=bench.FOG_SIGMA_T)
+    ap.add_argument("--sphere", action="store_true", help="add the reference's sphere (main.cpp:75)")
     args = ap.parse_args()
     pkg = graft.load_package()
     api, abi = pkg.api, pkg.abi
     S = args.size
-    tris = api.load_test_model(abi.SCENE_GLASS_CUBE)
-    cam, light = api.default_camera(S), api.default_light(glass=True)
-    p = api.default_params(S, S, rng_mode=abi.RNG_COUNTER, seed=0, fog_sigma_t=bench.FOG_SIGMA_T,
-                           fog_albedo=bench.FOG_ALBEDO)
-    sc = api.Scene(tris)
+    tris = api.load_test_model(args.scene)
+    spheres = api.make_sphere(0.3, [-0.45, 0.7, -0.55, 1], [1, 0, 0]) if args.sphere else None
+    cam, light = api.default_camera(S), api.default_light(glass=args.scene != 0)
+    p = api.default_params(S, S, rng_mode=abi.RNG_COUNTER if args.rng == "counter" else abi.RNG_MINSTD_PATH, seed=0,
+                           fog_sigma_t=args.fog, fog_albedo=bench.FOG_ALBEDO)
+    sc = api.Scene(tris, spheres)
     t0 = time.time()
     acc = sc.render_accumulate(cam, light, p, 0, args.spp)
     t_gpu = time.time() - t0
@@ -42,12 +47,12 @@ def main():
     t0 = time.time()
     want = None
     for b in range(0, args.spp, 16):
-        img, _ = O.render_accumulate(tris, None, cam, light, p, b, min(16, args.spp - b), threads=args.threads)
+        img, _ = O.render_accumulate(tris, spheres, cam, light, p, b, min(16, args.spp - b), threads=args.threads)
         want = img.copy() if want is None else (want + img).astype(np.float32)
         print(f"  oracle: {b + 16} of {args.spp} samples, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
     a = np.ascontiguousarray(acc).view(np.uint32)
     w = np.ascontiguousarray(want).view(np.uint32)
-    print(json.dumps({"workload": f"GlassCube {S}x{S}, {args.spp} spp, fog, counter RNG", "paths": S * S * args.spp,
+    print(json.dumps({"workload": f"test model {args.scene}{' + sphere' if args.sphere else ''} {S}x{S}, {args.spp} spp, fog sigma_t {args.fog}, {args.rng} RNG", "paths": S * S * args.spp,
                       "channel_sums": int(a.size), "differing": int(np.count_nonzero(a != w)),
                       "gpu_seconds_incl_copies": round(t_gpu, 3), "oracle_seconds": round(time.time() - t0, 1),
                       "oracle_threads": args.threads}), flush=True)
