@@ -1131,14 +1131,16 @@ __global__ __launch_bounds__(BLOCK) void k_selfcheck_scan(DeviceScene sc, unsign
   }
 }
 
-// accum[i] += sum over chunks (in chunk order) of partial[c][i]
+// accum[i] = (((accum[i] + partial[0][i]) + partial[1][i]) + ...): the item sums join the running sum one
+// by one, in sample order. Adding samples [a, b) and then [b, c) therefore leaves the very bits that
+// adding [a, c) at once leaves, whenever b - a is a whole number of work items.
 __global__ __launch_bounds__(BLOCK) void k_reduce_chunks(const float* __restrict__ partial, uint32_t n_chunks,
                                                          size_t n, float* __restrict__ accum) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
-  float s = partial[i];
-  for (uint32_t c = 1; c < n_chunks; ++c) s += partial[(size_t)c * n + i];
-  accum[i] += s;
+  float s = accum[i];
+  for (uint32_t c = 0; c < n_chunks; ++c) s += partial[(size_t)c * n + i];
+  accum[i] = s;
 }
 
 // main.cpp:141-145 + PutPixelSDL (SDLauxiliary.h:149-161)

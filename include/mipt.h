@@ -235,7 +235,11 @@ int mipt_any_hit(MiptScene* scene, const float* origin4, const float* dir4,
  * [sample_begin, sample_begin + sample_count) of every pixel, and ADDS the
  * radiance sums into the caller's accumulation buffer: accum_rgb is a host
  * float[width*height*3], pixel (x, y) at ((x*height)+y)*3 -- x-major, like the
- * reference's `vec3** pixels` columns (main.cpp:55-57). */
+ * reference's `vec3** pixels` columns (main.cpp:55-57).
+ * Association of the sums: a pixel's samples are added 16 at a time (in sample order, from zero), and
+ * these sums join the buffer's running value one by one in sample order. Adding [a, b) and then
+ * [b, c) therefore leaves the very bits that adding [a, c) in one call leaves whenever b - a is a
+ * multiple of 16; a split elsewhere agrees to rounding. */
 int mipt_render_accumulate(MiptScene* scene, const MiptCamera* cam, const MiptLight* light,
                            const MiptParams* params, uint32_t sample_begin,
                            uint32_t sample_count, float* accum_rgb);
@@ -279,7 +283,8 @@ int mipt_resolve_argb_dev(MiptScene* scene, const float* d_accum_rgb, int width,
  * path kernel and the ordered sum, all on `stream`.
  *   Limit: width * height * 12 bytes * ceil(sample_count / 16) <= MIPT_NOALLOC_MAX_BYTES
  *   (1024 x 1024 at up to 32 samples per call, 512 x 512 at up to 160); larger calls return
- *   MIPT_E_INVALID -- split the sample range over several calls, ranges compose exactly.
+ *   MIPT_E_INVALID -- split the sample range over several calls of a multiple of 16 samples: the
+ *   ranges compose bit for bit (see mipt_render_accumulate).
  *   The array is shared by every scene and stream on a GPU (each GPU has its own copy, resident
  *   until the process ends): two such calls that overlap on one GPU race; issue them on one stream
  *   or order them yourself. mipt_get_stats' kernel_ms is not updated by this call. */

@@ -68,8 +68,8 @@ def test_gpu_converged_image_matches_oracle(pkg, O, name):
     else:
         assert same >= 0.99
     assert rmse <= 0.1 and worst <= 2.0
-    dp = display(parts, CF.SPP) - display(ref, CF.SPP)
-    assert np.sqrt((dp ** 2).mean()) <= 0.1
+    # four calls of 256 samples leave the bits one call of 1024 leaves
+    assert np.array_equal(np.ascontiguousarray(parts).view(np.uint32), np.ascontiguousarray(acc).view(np.uint32))
     # the oracle in the GPU's association: work items of 16 samples, item sums added in sample order
     blocked = None
     for c in range(CF.SPP // 16):
