@@ -314,8 +314,10 @@ def cornell_workload(args):
         global_spp = SPP_CONFIG2 if strong else SPP_CONFIG1 * world
     n_img = SIZE * SIZE * 3
     step_buf = torch.zeros(n_img, dtype=torch.float32, device=dev)
-    total = torch.zeros(n_img, dtype=torch.float32, device=dev) if rank == 0 else None
-    my_spp = parallel.rank_sample_range(0, global_spp, rank, world)[1]
+    # --exact: the running image exists on every rank (it travels through them); else rank 0 sums
+    total = torch.zeros(n_img, dtype=torch.float32, device=dev) if rank == 0 or args.exact else None
+    split = parallel.rank_item_range if args.exact else parallel.rank_sample_range
+    my_spp = split(0, global_spp, rank, world)[1]
 
     def render(begin, count, image):
         scene.render_accumulate_dev(cam, light, params, begin, count, image)
@@ -323,8 +325,14 @@ def cornell_workload(args):
     kernel_ms = []
 
     def one_step(k):
-        # the step's global sample range is split into `world` contiguous sub-ranges; one sum-reduce
-        parallel.render_distributed(render, k * global_spp, global_spp, rank, world, step_buf, total,
+        if args.exact:
+            # every rank traces its whole work items at once, then the image makes the round of the ranks
+            # and each folds its items in: the bits ONE GPU would leave, whatever the number of ranks
+            parallel.render_chained(lambda b, c: scene.render_items_dev(cam, light, params, b, c), scene.fold_items_dev,
+                                    k * global_spp, global_spp, rank, world, total, via_host=args.rehearse)
+        else:
+            # the step's global sample range is split into `world` contiguous sub-ranges; one sum-reduce
+            parallel.render_distributed(render, k * global_spp, global_spp, rank, world, step_buf, total,
                                         via_host=args.rehearse)
         if k >= args.warmup and rank == 0:
             kernel_ms.append(scene.stats().kernel_ms)  # HIP events around the path kernel on its launch stream
@@ -370,8 +378,11 @@ def cornell_workload(args):
             "config": {"workload": f"GlassCube Cornell box (22 triangles: red room, glass block, mirror) "
                                    f"{SIZE}x{SIZE}, {global_spp} spp per step, max depth 10, fog sigma_t="
                                    f"{FOG_SIGMA_T} albedo={FOG_ALBEDO}, counter-based RNG; {cfg}"
-                                   + (f": samples split over {world} GPUs ({my_spp} each) + one RCCL sum-reduce "
-                                      f"of the fp32 image per step" if world > 1 else ""),
+                                   + ((f": samples split over {world} GPUs ({my_spp} on rank 0) in whole work items; the image "
+                                       f"makes the round of the GPUs and each folds its items in -- bit-identical to one GPU")
+                                      if world > 1 and args.exact else
+                                      (f": samples split over {world} GPUs ({my_spp} each) + one RCCL sum-reduce "
+                                       f"of the fp32 image per step") if world > 1 else ""),
                        "spp_per_gpu_per_step": my_spp, "global_spp_per_step": global_spp,
                        "parallelism": f"spp-split x{world}"},
             "mrays_per_s": value * rays_per_path / 1e6,
@@ -425,6 +436,9 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a one-GPU machine: all ranks on GPU 0, gloo instead of RCCL, images reduced through "
                          "the host. Checks the N-rank code path; the line says so and its timings mean nothing")
+    ap.add_argument("--exact", action="store_true",
+                    help="cornell, N > 1: instead of the sum-reduce, pass the image from rank to rank, each folding "
+                         "its work items in (parallel.render_chained): the N-GPU image is the 1-GPU image bit for bit")
     ap.add_argument("--save-total", default=None, metavar="FILE.npy",
                     help="cornell: rank 0 saves the image summed over all warm-up and timed steps (for checks)")
     ap.add_argument("--workload", choices=["cornell", "c4", "c5"], default="cornell",

@@ -91,6 +91,7 @@ EXPORTS = [
     "mipt_render_accumulate_noalloc_dev", "mipt_scene_create_opts",
     "mipt_multi_create", "mipt_multi_destroy", "mipt_multi_device_count", "mipt_multi_render_accumulate",
     "mipt_multi_sample_range", "mipt_multi_scene", "mipt_frame_poll",
+    "mipt_render_items_dev", "mipt_fold_items_dev", "mipt_multi_render_accumulate_chained", "mipt_multi_item_range",
 ]
 
 
@@ -112,6 +113,14 @@ def load_library(path=None):
         raise MiptLibraryMissing(
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch ships a HIP runtime of its own (torch/lib/libamdhip64.so) and libmipt.so names the
+    # system's by the same soname: whichever the process loads first serves both. Loaded second,
+    # torch finds no GPU through the other one; so torch goes first wherever it is installed (the
+    # *_dev methods take its tensors anyway). A C++ host has no such concern.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     P = C.POINTER
     vp = C.c_void_p
@@ -137,6 +146,8 @@ def load_library(path=None):
                                                C.c_uint32, C.c_uint32, f32p, vp]
     lib.mipt_resolve_argb_dev.argtypes = [vp, f32p, C.c_int, C.c_int, C.c_uint32, u32p, vp]
     lib.mipt_render_accumulate_noalloc_dev.argtypes = lib.mipt_render_accumulate_dev.argtypes
+    lib.mipt_render_items_dev.argtypes = [vp, P(MiptCamera), P(MiptLight), P(MiptParams), C.c_uint32, C.c_uint32, vp]
+    lib.mipt_fold_items_dev.argtypes = [vp, f32p, vp]
     lib.mipt_get_stats.argtypes = [vp, P(MiptStats)]
     lib.mipt_multi_create.argtypes = [vp, C.c_size_t, vp, C.c_size_t, P(C.c_int), C.c_int, P(vp)]
     lib.mipt_multi_destroy.argtypes = [vp]
@@ -148,6 +159,9 @@ def load_library(path=None):
                                                  C.c_uint32, C.c_uint32, f32p]
     lib.mipt_multi_sample_range.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, P(C.c_uint32), P(C.c_uint32)]
     lib.mipt_multi_sample_range.restype = None
+    lib.mipt_multi_item_range.argtypes = lib.mipt_multi_sample_range.argtypes
+    lib.mipt_multi_item_range.restype = None
+    lib.mipt_multi_render_accumulate_chained.argtypes = lib.mipt_multi_render_accumulate.argtypes
     lib.mipt_path_key.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     lib.mipt_path_key.restype = C.c_uint32
     lib.mipt_debug_selfcheck.argtypes = [vp, C.c_uint64, C.c_uint32, P(C.c_uint64 * 8)]

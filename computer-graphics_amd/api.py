@@ -243,6 +243,17 @@ class Scene:
                                                     C.byref(params), sample_begin, sample_count,
                                                     accum.data_ptr(), self._stream()))
 
+    def render_items_dev(self, cam, light, params, sample_begin, sample_count):
+        """First half of render_accumulate_dev: the work items' sums stay in the scene's scratch."""
+        _check(self._lib.mipt_render_items_dev(self._h, C.byref(cam), C.byref(light), C.byref(params),
+                                               sample_begin, sample_count, self._stream()))
+
+    def fold_items_dev(self, accum):
+        """Second half: the pending item sums join accum's running values in sample order."""
+        if not accum.is_contiguous():
+            raise ValueError("accum must be a contiguous float32 tensor of W*H*3 elements")
+        _check(self._lib.mipt_fold_items_dev(self._h, accum.data_ptr(), self._stream()))
+
     def render_accumulate_noalloc_dev(self, cam, light, params, sample_begin, sample_count, accum):
         """render_accumulate_dev through the entry point that allocates nothing (fixed scratch in the
         library, at most abi.NOALLOC_MAX_BYTES of item sums per call)."""
@@ -350,8 +361,25 @@ class MultiScene:
                                                       sample_begin, sample_count, _ptr(accum)))
         return accum
 
+    def render_accumulate_chained(self, cam, light, params, sample_begin, sample_count, accum=None):
+        """The one-GPU image bit for bit: whole work items per device, the image handed from device to device."""
+        W, H = params.width, params.height
+        if accum is None:
+            accum = np.zeros((W, H, 3), dtype=np.float32)
+        if accum.dtype != np.float32 or accum.shape != (W, H, 3) or not accum.flags.c_contiguous:
+            raise ValueError("accum must be a C-contiguous float32 (W, H, 3) array")
+        _check(self._lib.mipt_multi_render_accumulate_chained(self._h, C.byref(cam), C.byref(light), C.byref(params),
+                                                              sample_begin, sample_count, _ptr(accum)))
+        return accum
+
 
 def multi_sample_range(begin, count, rank, n):
     b, c = C.c_uint32(), C.c_uint32()
     abi.load_library().mipt_multi_sample_range(begin, count, rank, n, C.byref(b), C.byref(c))
+    return int(b.value), int(c.value)
+
+
+def multi_item_range(begin, count, rank, n):
+    b, c = C.c_uint32(), C.c_uint32()
+    abi.load_library().mipt_multi_item_range(begin, count, rank, n, C.byref(b), C.byref(c))
     return int(b.value), int(c.value)

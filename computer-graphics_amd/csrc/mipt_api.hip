@@ -114,6 +114,10 @@ struct MiptScene {
   // counters); the next such launch waits for it, so calls on different streams do not overlap
   hipEvent_t ev_busy = nullptr;
   bool busy_valid = false;
+  // item sums left in d_partial by mipt_render_items_dev, waiting for mipt_fold_items_dev
+  bool items_pending = false;
+  uint32_t items_sblocks = 0;
+  size_t items_n_img = 0;
   bool timed = false;
   bool stats_valid = false;
   uint64_t last_paths = 0;
@@ -988,20 +992,25 @@ static int render_launch(MiptScene* s, const MiptCamera* cam, const MiptLight* l
   launch_paths<false>(s, a, dim3(grid), lds, st);
   HIP_TRY(hipGetLastError());
   if (timed) HIP_TRY(hipEventRecord(s->ev1, st));
-  hipLaunchKernelGGL(k_reduce_chunks, dim3(grid_for(r.n_img)), dim3(BLOCK), 0, st, scr.sums, r.n_sblocks, r.n_img,
-                     d_accum_rgb);
-  HIP_TRY(hipGetLastError());
+  if (d_accum_rgb) {  // null: the item sums stay in the scratch for mipt_fold_items_dev
+    hipLaunchKernelGGL(k_reduce_chunks, dim3(grid_for(r.n_img)), dim3(BLOCK), 0, st, scr.sums, r.n_sblocks, r.n_img,
+                       d_accum_rgb);
+    HIP_TRY(hipGetLastError());
+  }
   if (timed) s->timed = true;
   s->stats_valid = stats;
   s->last_paths = (uint64_t)p->width * p->height * sample_count;
   return MIPT_OK;
 }
 
-extern "C" int mipt_render_accumulate_dev(MiptScene* s, const MiptCamera* cam, const MiptLight* light,
-                                          const MiptParams* p, uint32_t sample_begin, uint32_t sample_count,
-                                          float* d_accum_rgb, void* stream) {
-  int rc = render_check(s, cam, light, p, sample_begin, sample_count, d_accum_rgb);
+// mipt_render_accumulate_dev, or (d_accum_rgb null) its first half: the item sums stay in the scene's scratch
+static int render_dev(MiptScene* s, const MiptCamera* cam, const MiptLight* light, const MiptParams* p,
+                      uint32_t sample_begin, uint32_t sample_count, float* d_accum_rgb, bool fold, void* stream) {
+  static float not_null;  // render_check wants a buffer; the first half has none
+  int rc = render_check(s, cam, light, p, sample_begin, sample_count, fold ? d_accum_rgb : &not_null);
   if (rc != MIPT_OK) return rc;
+  if (s->items_pending)
+    return fail(MIPT_E_INVALID, "mipt_render_*: the items of the last mipt_render_items_dev have not been folded");
   if (sample_count == 0) return MIPT_OK;
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
@@ -1019,9 +1028,41 @@ extern "C" int mipt_render_accumulate_dev(MiptScene* s, const MiptCamera* cam, c
   }
   rc = scratch_acquire(s, st);
   if (rc != MIPT_OK) return rc;
-  rc = render_launch(s, cam, light, p, sample_begin, sample_count, d_accum_rgb, st, r,
+  rc = render_launch(s, cam, light, p, sample_begin, sample_count, fold ? d_accum_rgb : nullptr, st, r,
                      RenderScratch{s->d_queue, s->d_partial}, true);
   if (rc != MIPT_OK) return rc;
+  if (!fold) { s->items_pending = true; s->items_sblocks = r.n_sblocks; s->items_n_img = r.n_img; }
+  return scratch_release(s, st);
+}
+
+extern "C" int mipt_render_accumulate_dev(MiptScene* s, const MiptCamera* cam, const MiptLight* light,
+                                          const MiptParams* p, uint32_t sample_begin, uint32_t sample_count,
+                                          float* d_accum_rgb, void* stream) {
+  return render_dev(s, cam, light, p, sample_begin, sample_count, d_accum_rgb, true, stream);
+}
+
+// The two halves of mipt_render_accumulate_dev. Between them the item sums sit in the scene's
+// scratch; the fold may run on another stream (it waits for the render through the scene's event)
+// and into a buffer that did not exist when the render began -- e.g. the image another GPU has just
+// sent, which is how several GPUs produce the bits one GPU produces.
+extern "C" int mipt_render_items_dev(MiptScene* s, const MiptCamera* cam, const MiptLight* light,
+                                     const MiptParams* p, uint32_t sample_begin, uint32_t sample_count,
+                                     void* stream) {
+  return render_dev(s, cam, light, p, sample_begin, sample_count, nullptr, false, stream);
+}
+
+extern "C" int mipt_fold_items_dev(MiptScene* s, float* d_accum_rgb, void* stream) {
+  if (!s) return fail(MIPT_E_INVALID, "mipt_fold_items_dev: scene is null");
+  if (!d_accum_rgb) return fail(MIPT_E_INVALID, "mipt_fold_items_dev: accumulation buffer is null");
+  if (!s->items_pending) return MIPT_OK;  // nothing rendered (a range of zero samples): the image stays as it is
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t st = (hipStream_t)stream;
+  int rc = scratch_acquire(s, st);
+  if (rc != MIPT_OK) return rc;
+  hipLaunchKernelGGL(k_reduce_chunks, dim3(grid_for(s->items_n_img)), dim3(BLOCK), 0, st, s->d_partial, s->items_sblocks,
+                     s->items_n_img, d_accum_rgb);
+  HIP_TRY(hipGetLastError());
+  s->items_pending = false;
   return scratch_release(s, st);
 }
 

@@ -86,6 +86,7 @@ struct Part {
   hipStream_t stream = nullptr;
   float* d_image = nullptr;  // this device's samples of the current call
   ncclComm_t comm = nullptr;
+  hipEvent_t folded = nullptr;  // chained rendering: this device's items are in its image
 };
 
 }  // namespace
@@ -106,6 +107,19 @@ extern "C" void mipt_multi_sample_range(uint32_t begin, uint32_t count, int rank
   *part_count = base + (r < extra ? 1u : 0u);
 }
 
+// the same split in whole work items (16 samples): every share a multiple of 16 but the last one in use
+extern "C" void mipt_multi_item_range(uint32_t begin, uint32_t count, int rank, int n, uint32_t* part_begin,
+                                      uint32_t* part_count) {
+  const uint32_t item = 16u;
+  const uint32_t n_items = count / item + (count % item ? 1u : 0u);
+  uint32_t first = 0, mine = 0;
+  mipt_multi_sample_range(0, n_items, rank, n, &first, &mine);
+  const uint64_t lo = (uint64_t)first * item, hi = (uint64_t)(first + mine) * item;
+  const uint32_t lo_c = lo < count ? (uint32_t)lo : count, hi_c = hi < count ? (uint32_t)hi : count;
+  *part_begin = begin + lo_c;
+  *part_count = hi_c - lo_c;
+}
+
 extern "C" void mipt_multi_destroy(MiptMulti* m) {
   if (!m) return;
   for (Part& p : m->parts) {
@@ -114,6 +128,7 @@ extern "C" void mipt_multi_destroy(MiptMulti* m) {
     if (p.stream) (void)hipStreamSynchronize(p.stream);
     if (p.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p.comm);
     if (p.d_image) (void)hipFree(p.d_image);
+    if (p.folded) (void)hipEventDestroy(p.folded);
     if (p.stream) (void)hipStreamDestroy(p.stream);
     if (p.scene) mipt_scene_destroy(p.scene);
   }
@@ -136,6 +151,7 @@ static int multi_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
     if (rc != MIPT_OK) return rc;
     HIP_TRY(hipSetDevice(p.device));
     HIP_TRY(hipStreamCreate(&p.stream));
+    HIP_TRY(hipEventCreateWithFlags(&p.folded, hipEventDisableTiming));
   }
   std::vector<ncclComm_t> comms((size_t)n_devices);
   RCCL_TRY(g_rccl.CommInitAll(comms.data(), n_devices, devices));
@@ -229,5 +245,58 @@ extern "C" int mipt_multi_render_accumulate(MiptMulti* m, const MiptCamera* cam,
     HIP_TRY(hipStreamSynchronize(m->parts[(size_t)r].stream));
   }
   for (size_t i = 0; i < n; ++i) accum_rgb[i] += m->h_total[i];  // main.cpp:137, for the whole range at once
+  return MIPT_OK;
+}
+
+// The image ONE device would produce, from all of them: every device traces the whole work items of
+// its share at once; the caller's image goes to the first device and then from device to device
+// (peer copies), each folding its items into it in sample order; the last one hands it back.
+// No collective and no RCCL call: the order of the additions is the one-device order.
+extern "C" int mipt_multi_render_accumulate_chained(MiptMulti* m, const MiptCamera* cam, const MiptLight* light,
+                                                    const MiptParams* params, uint32_t sample_begin,
+                                                    uint32_t sample_count, float* accum_rgb) {
+  if (!m || !params || !accum_rgb) return fail(MIPT_E_INVALID, "mipt_multi_render_accumulate_chained: null argument");
+  if (params->width <= 0 || params->height <= 0 || params->width > 32768 || params->height > 32768)
+    return fail(MIPT_E_INVALID, "mipt_multi_render_accumulate_chained: image size out of range");
+  if (sample_count == 0) return MIPT_OK;
+  const size_t n = (size_t)params->width * params->height * 3;
+  int rc = ensure_images(m, n);
+  if (rc != MIPT_OK) return rc;
+  const int world = (int)m->parts.size();
+  std::vector<uint32_t> counts((size_t)world);
+  for (int r = 0; r < world; ++r) {  // all devices trace at once
+    Part& p = m->parts[(size_t)r];
+    uint32_t b = 0, c = 0;
+    mipt_multi_item_range(sample_begin, sample_count, r, world, &b, &c);
+    counts[(size_t)r] = c;
+    if (!c) continue;
+    rc = mipt_render_items_dev(p.scene, cam, light, params, b, c, p.stream);
+    if (rc != MIPT_OK) return rc;
+  }
+  memcpy(m->h_total, accum_rgb, n * sizeof(float));
+  for (int r = 0; r < world; ++r) {  // the image's round: upload / peer copy, fold, mark
+    Part& p = m->parts[(size_t)r];
+    HIP_TRY(hipSetDevice(p.device));
+    if (r == 0) {
+      HIP_TRY(hipMemcpyAsync(p.d_image, m->h_total, n * sizeof(float), hipMemcpyHostToDevice, p.stream));
+    } else {
+      Part& q = m->parts[(size_t)r - 1];
+      HIP_TRY(hipStreamWaitEvent(p.stream, q.folded, 0));
+      HIP_TRY(hipMemcpyPeerAsync(p.d_image, p.device, q.d_image, q.device, n * sizeof(float), p.stream));
+    }
+    if (counts[(size_t)r]) {
+      rc = mipt_fold_items_dev(p.scene, p.d_image, p.stream);
+      if (rc != MIPT_OK) return rc;
+    }
+    HIP_TRY(hipEventRecord(p.folded, p.stream));
+  }
+  Part& last = m->parts[(size_t)world - 1];
+  HIP_TRY(hipSetDevice(last.device));
+  HIP_TRY(hipMemcpyAsync(m->h_total, last.d_image, n * sizeof(float), hipMemcpyDeviceToHost, last.stream));
+  for (int r = 0; r < world; ++r) {
+    HIP_TRY(hipSetDevice(m->parts[(size_t)r].device));
+    HIP_TRY(hipStreamSynchronize(m->parts[(size_t)r].stream));
+  }
+  memcpy(accum_rgb, m->h_total, n * sizeof(float));
   return MIPT_OK;
 }

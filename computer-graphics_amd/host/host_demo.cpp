@@ -3,8 +3,9 @@
 // `closestIntersection` for single rays and `Draw` into a `screen` buffer. The vector types below
 // carry the member names the reference's glm types have (glm itself is not needed here).
 //
-//   host_demo <scene 0..3> <size> <frames> <samples_per_frame> [multi]
-// (multi: Draw goes through mipt_host::MultiGpuScene on device 0 -- the several-GPU path with one rank)
+//   host_demo <scene 0..3> <size> <frames> <samples_per_frame> [multi|multi-reduce]
+// (multi: Draw goes through mipt_host::MultiGpuScene on device 0 -- the several-GPU path with one rank,
+//  image handed from device to device; multi-reduce: the RCCL sum-reduce of the per-device images)
 // prints one line of key=value results that tests/test_gpu_host_cpp.py compares with the
 // Python host's results for the same inputs.
 #include <cstdio>
@@ -38,7 +39,8 @@ int main(int argc, char** argv) {
   const int size = argc > 2 ? atoi(argv[2]) : 64;
   const int frames = argc > 3 ? atoi(argv[3]) : 2;
   const int spf = argc > 4 ? atoi(argv[4]) : 4;
-  const bool multi = argc > 5 && strcmp(argv[5], "multi") == 0;
+  const bool reduce = argc > 5 && strcmp(argv[5], "multi-reduce") == 0;
+  const bool multi = reduce || (argc > 5 && strcmp(argv[5], "multi") == 0);
   try {
     MiptTriangle raw[30];
     const int n = mipt_load_test_model(which, raw, 30);
@@ -88,6 +90,7 @@ int main(int argc, char** argv) {
     int samplesSeenSoFar = 0;
     if (multi) {
       mipt_host::MultiGpuScene all(triangles, spheres, std::vector<int>{0});
+      all.sum_reduce = reduce;
       for (int f = 0; f < frames; ++f) mipt_host::Draw(all, &scr, cam, light, pixels, samplesSeenSoFar, spf);
     } else {
       for (int f = 0; f < frames; ++f) mipt_host::Draw(gpu, &scr, cam, light, pixels, samplesSeenSoFar, spf);

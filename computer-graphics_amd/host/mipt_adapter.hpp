@@ -174,8 +174,10 @@ inline void Draw(GpuScene& gpu, ScreenT* screen, const CameraT& cam, const Light
 }
 
 // The scene on several GPUs of the node, driven from this one process: what the OpenMP loop over
-// image columns (main.cpp:121) becomes. Draw() below splits every call's samples over the devices;
-// the library sums the per-device images with one RCCL reduce.
+// image columns (main.cpp:121) becomes. Draw() below splits every call's samples over the devices.
+// By default the image is handed from device to device, each adding its samples in the order one GPU
+// adds them (mipt_multi_render_accumulate_chained): the pixels are those of a one-GPU run bit for bit.
+// sum_reduce = true takes one RCCL reduce of the per-device images instead (equal up to rounding).
 class MultiGpuScene {
  public:
   template <class TriangleT, class SphereT>
@@ -194,6 +196,7 @@ class MultiGpuScene {
   MiptMulti* handle() const { return h_; }
   MiptParams params;
   bool params_set = false;
+  bool sum_reduce = false;
 
  private:
   MiptMulti* h_ = nullptr;
@@ -214,8 +217,8 @@ inline void Draw(MultiGpuScene& gpu, ScreenT* screen, const CameraT& cam, const 
     }
   const MiptCamera c = to_mipt_camera(cam);
   const MiptLight l = to_mipt_light(light);
-  check(mipt_multi_render_accumulate(gpu.handle(), &c, &l, &gpu.params, (uint32_t)samplesSeenSoFar,
-                                     (uint32_t)samples_per_call, accum.data()));
+  check((gpu.sum_reduce ? mipt_multi_render_accumulate : mipt_multi_render_accumulate_chained)(
+      gpu.handle(), &c, &l, &gpu.params, (uint32_t)samplesSeenSoFar, (uint32_t)samples_per_call, accum.data()));
   samplesSeenSoFar += samples_per_call;
   for (int x = 0; x < W; ++x)
     for (int y = 0; y < H; ++y) {

@@ -270,6 +270,37 @@ def test_bench_frame_at_full_resolution_is_the_oracle_frame(api, O, pkg):
     assert want.sum() > 0 and np.array_equal(bits(acc), bits(want)), np.count_nonzero(bits(acc) != bits(want))
 
 
+def test_render_items_and_fold_are_the_two_halves(api, O, pkg):
+    # mipt_render_items_dev + mipt_fold_items_dev == mipt_render_accumulate_dev, bit for bit; the fold may
+    # run on another stream and into an image that holds earlier samples; the items of one render at a time
+    import torch
+    abi = pkg.abi
+    W, H = 96, 80
+    tris = O.load_test_model(2)
+    cam, light = O.default_camera(W), O.default_light(True)
+    p = O.default_params(W, H, seed=8, rng_mode=abi.RNG_COUNTER, fog_sigma_t=0.1)
+    sc = api.Scene(tris)
+    whole = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    sc.render_accumulate_dev(cam, light, p, 0, 80, whole)
+    halves = torch.zeros_like(whole)
+    sc.render_items_dev(cam, light, p, 0, 48)
+    with pytest.raises(api.MiptError):            # unfolded items: no second render on this scene
+        sc.render_items_dev(cam, light, p, 48, 32)
+    with pytest.raises(api.MiptError):
+        sc.render_accumulate_dev(cam, light, p, 48, 32, halves)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                 # the fold waits for the render through the scene's event
+        sc.fold_items_dev(halves)
+        sc.fold_items_dev(halves)                 # nothing pending: leaves the image alone
+    side.synchronize()
+    sc.render_items_dev(cam, light, p, 48, 32)
+    sc.fold_items_dev(halves)
+    torch.cuda.synchronize()
+    sc.close()
+    assert whole.abs().sum().item() > 0
+    assert torch.equal(whole.view(torch.int32), halves.view(torch.int32))
+
+
 def test_render_sample_ranges_compose(api, O):
     # samples [0,64) in one call == [0,32) then [32,64) accumulated, bit for bit: the stream of a path
     # depends only on (pixel, sample index), and the sums of the work items (16 samples each) join the
