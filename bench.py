@@ -223,14 +223,19 @@ def tree_workload(args):
                                     fog_albedo=FOG_ALBEDO)
         scene = api.Scene(tris, None, device=dev.index)
         buf = torch.zeros(SIZE * SIZE * 3, dtype=torch.float32, device=dev)
-        total = torch.zeros_like(buf) if rank == 0 else None
+        total = torch.zeros_like(buf) if rank == 0 or args.exact else None
 
         def render(begin, count, image):
             scene.render_accumulate_dev(cam, light, params, begin, count, image)
 
         def step(k):
-            parallel.render_distributed(render, k * global_spp, global_spp, rank, world, buf, total,
+            if args.exact:   # the image relayed through the ranks: the one-GPU image bit for bit
+                parallel.render_chained(lambda b, c: scene.render_items_dev(cam, light, params, b, c),
+                                        scene.fold_items_dev, k * global_spp, global_spp, rank, world, total,
                                         via_host=args.rehearse)
+            else:
+                parallel.render_distributed(render, k * global_spp, global_spp, rank, world, buf, total,
+                                            via_host=args.rehearse)
         units_per_step, unit = SIZE * SIZE * global_spp, "paths/s"
         label = (f"empty Cornell room + 102 400-triangle glass mesh (LBVH), {SIZE}x{SIZE}, {global_spp} spp per step"
                  f"{' split over the GPUs' if world > 1 else ''}, fog on; stand-in for BASELINE configs[3]")
@@ -437,7 +442,7 @@ def main():
                     help="N > 1 on a one-GPU machine: all ranks on GPU 0, gloo instead of RCCL, images reduced through "
                          "the host. Checks the N-rank code path; the line says so and its timings mean nothing")
     ap.add_argument("--exact", action="store_true",
-                    help="cornell, N > 1: instead of the sum-reduce, pass the image from rank to rank, each folding "
+                    help="cornell and c4, N > 1: instead of the sum-reduce, pass the image from rank to rank, each folding "
                          "its work items in (parallel.render_chained): the N-GPU image is the 1-GPU image bit for bit")
     ap.add_argument("--save-total", default=None, metavar="FILE.npy",
                     help="cornell: rank 0 saves the image summed over all warm-up and timed steps (for checks)")
