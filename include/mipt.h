@@ -316,6 +316,8 @@ int mipt_render_accumulate_noalloc_dev(MiptScene* scene, const MiptCamera* cam, 
  *                           the camera or the light moved
  *   mipt_frame_add_samples  Draw's pixel loop (main.cpp:121-139) for n more samples of every pixel,
  *                           continuing the sample index; asynchronous (the frame's own stream)
+ *                           (added 16, or a multiple of 16, at a time the image is at every moment the
+ *                           one a single call for all its samples would have left, bit for bit)
  *   mipt_frame_present      Draw's tonemap loop (main.cpp:141-145) into the host screen buffer; waits
  *                           for the samples added so far
  *   mipt_frame_read_pixels  the accumulated sums, x-major W*H*3 floats (the reference's `pixels`)

@@ -552,6 +552,11 @@ def test_progressive_frame_equals_host_round_trips(api, O):
         assert polls < 10 ** 7
     whole = fr.read_pixels()
     assert np.allclose(whole, acc, rtol=2e-6, atol=1e-7)   # one call of 12 = 1 + 4 + 7 up to the order of the sums
+    # in whole work items the progressive image is THE image: 16 + 32 + 16 samples = one call of 64
+    fr.reset()
+    for n in (16, 32, 16):
+        fr.add_samples(cam, light, p, n)
+    assert np.array_equal(bits(fr.read_pixels()), bits(sc.render_accumulate(cam, light, p, 0, 64)))
     fr.close()
     sc.close()
 
