@@ -301,6 +301,24 @@ def test_render_items_and_fold_are_the_two_halves(api, O, pkg):
     assert torch.equal(whole.view(torch.int32), halves.view(torch.int32))
 
 
+@pytest.mark.parametrize("W,H,spp", [(1, 1, 40), (1, 9, 17), (3, 2500, 3), (4097, 1, 2), (9, 8, 16), (8, 8, 1)])
+def test_odd_image_shapes_are_the_oracle_images(api, O, pkg, W, H, spp):
+    # one pixel, single rows and columns, sizes around the 8 x 8 tiles the work queue hands out
+    tris = O.load_test_model(2)
+    cam, light = O.default_camera(max(W, H)), O.default_light(True)
+    p = O.default_params(W, H, seed=13, rng_mode=pkg.abi.RNG_COUNTER, fog_sigma_t=0.1)
+    sc = api.Scene(tris)
+    acc = sc.render_accumulate(cam, light, p, 5, spp)
+    screen = sc.resolve_argb(acc, spp)
+    sc.close()
+    want = None
+    for b in range(0, spp, 16):
+        img, _ = O.render_accumulate(tris, None, cam, light, p, 5 + b, min(16, spp - b))
+        want = img.copy() if want is None else (want + img).astype(np.float32)
+    assert acc.shape == (W, H, 3) and np.array_equal(bits(acc), bits(want))
+    assert np.array_equal(screen, O.resolve_argb(want, spp))
+
+
 def test_render_sample_ranges_compose(api, O):
     # samples [0,64) in one call == [0,32) then [32,64) accumulated, bit for bit: the stream of a path
     # depends only on (pixel, sample index), and the sums of the work items (16 samples each) join the
