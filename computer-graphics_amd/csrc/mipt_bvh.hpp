@@ -652,13 +652,17 @@ __device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, const DeviceSce
 // OR over the triangles, the walk stops at the first acceptance.
 // Returns when the lane's walk is done or when fewer than BVH_KEEP_NUM / BVH_KEEP_DEN of the lanes
 // that entered are still walking.
-template <int KEEP_NUM = BVH_KEEP_NUM, int KEEP_DEN = BVH_KEEP_DEN, typename STK>
+// SET_ASIDE = false (the any-hit batch kernel): a lane that meets a leaf waits for the leaf round instead
+// of walking on. An any-hit walk most likely ENDS at its next leaf test, so the nodes it steps through
+// meanwhile are mostly wasted (10^6-triangle soup: +15 % any-hit rays/s, 102 k mesh +4 %); a closest-hit
+// walk has to visit them anyway, and in the path kernel, where the two kinds share waves, waiting lost 1-4 %.
+template <int KEEP_NUM = BVH_KEEP_NUM, int KEEP_DEN = BVH_KEEP_DEN, bool SET_ASIDE = true, typename STK>
 __device__ __forceinline__ void bvh_burst(BvhTrav& T, BvhMem& M, const STK& stack, const DeviceScene& sc,
                                           const BvhNode* __restrict__ nodes, BvhRay& r, bool shadow, float max_t,
                                           uint32_t& overflow) {
   const int entered = __popcll(__ballot(T.cur != BVH_DONE));
   while (T.cur != BVH_DONE) {
-    if (T.cur < 0 && T.pend == BVH_DONE && T.sp > 0) { T.pend = T.cur; T.cur = stack.pop(T.sp); }
+    if (SET_ASIDE && T.cur < 0 && T.pend == BVH_DONE && T.sp > 0) { T.pend = T.cur; T.cur = stack.pop(T.sp); }
     const int n_node = __popcll(__ballot(T.cur >= 0));
     const int n_leaf = __popcll(__ballot(T.pend != BVH_DONE || T.cur < 0));
     if (MIPT_BVH_VOTE_NODE * n_node >= MIPT_BVH_VOTE_LEAF * n_leaf) {

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_BATCH_OCC void k_bvh_batch(DeviceScene 
     if (!__any(have)) break;  // every lane idle: the queue has run dry
     if (have) {
       // refills are cheap here (two loads and the big-triangle filter): leave the walk when half is done
-      bvh_burst<1, 2>(T, M, stk, sc, sc.bvh, r, SHADOW, lim0, overflow);
+      bvh_burst<1, 2, !SHADOW>(T, M, stk, sc, sc.bvh, r, SHADOW, lim0, overflow);
       if (T.cur == BVH_DONE) {
         HitAcc h;
         h.set_lim(lim0);
