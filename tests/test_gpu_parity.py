@@ -319,6 +319,91 @@ def test_odd_image_shapes_are_the_oracle_images(api, O, pkg, W, H, spp):
     assert np.array_equal(screen, O.resolve_argb(want, spp))
 
 
+def moved_camera_and_light(O, width, yaw, pitch, steps_forward, light_shift, light_colour):
+    """What handleKeyboard (keyboard.cpp:5-76) leaves after some key presses: rotateY / rotateX
+    (camera.cpp:15-35) set the two rotation matrices, W moves the camera along Rx * Ry * (0, 0, 0.25, 0),
+    the arrow keys move the light."""
+    cam, light = O.default_camera(width), O.default_light(True)
+    cy, sy = np.float32(np.cos(np.float32(yaw))), np.float32(np.sin(np.float32(yaw)))
+    cx, sx = np.float32(np.cos(np.float32(pitch))), np.float32(np.sin(np.float32(pitch)))
+    ry = np.array([[cy, 0, -sy, 0], [0, 1, 0, 0], [sy, 0, cy, 0], [0, 0, 0, 1]], dtype=np.float32)   # rows = GLM columns
+    rx = np.array([[1, 0, 0, 0], [0, cx, sx, 0], [0, -sx, cx, 0], [0, 0, 0, 1]], dtype=np.float32)
+    cam.rot_y[:] = ry.ravel().tolist()
+    cam.rot_x[:] = rx.ravel().tolist()
+    step = (rx.T @ (ry.T @ np.array([0, 0, 0.25, 0], dtype=np.float32))).astype(np.float32)
+    pos = np.array(list(cam.pos), dtype=np.float32)
+    for _ in range(steps_forward):
+        pos = (pos + step).astype(np.float32)
+    cam.pos[:] = pos.tolist()
+    light.pos[:] = (np.array(list(light.pos), dtype=np.float32) + np.array(light_shift + [0], dtype=np.float32)).tolist()
+    light.color[:] = light_colour
+    return cam, light
+
+
+@pytest.mark.parametrize("scene", ["cornell", "glasscube"])
+def test_moved_camera_and_coloured_light(api, O, pkg, scene):
+    # every test above looks through reset_camera's camera at reset_light's white light; the
+    # interactive loop turns and moves the camera and the light before it calls Draw. Camera yawed,
+    # pitched and walked forward, light shifted and coloured (three channels, three divisions in
+    # directLight): image, ARGB screen, counters and listed paths against the oracle, bit for bit
+    abi = pkg.abi
+    which, glass = SCENES[scene]
+    tris = O.load_test_model(which)
+    W, H, spp = 120, 96, 48
+    cam, light = moved_camera_and_light(O, W, yaw=0.12, pitch=-0.08, steps_forward=2, light_shift=[-0.06, 0.04, 0.1],
+                                        light_colour=[12.0, 15.5, 9.25])
+    p = O.default_params(W, H, seed=6, rng_mode=abi.RNG_MINSTD_PATH, fog_sigma_t=0.05, flags=abi.FLAG_STATS)
+    sc = api.Scene(tris)
+    acc = sc.render_accumulate(cam, light, p, 0, spp)
+    st = sc.stats()
+    screen = sc.resolve_argb(acc, spp)
+    px, py, smp = path_list(W, H, 40_000, spp)
+    rgb, cnt = sc.trace_paths(cam, light, p, px, py, smp)
+    sc.close()
+    _, ost = O.render_accumulate(tris, None, cam, light, p, 0, spp, threads=8)
+    want = None
+    for b in range(0, spp, 16):
+        img, _ = O.render_accumulate(tris, None, cam, light, p, b, 16, threads=8)
+        want = img.copy() if want is None else (want + img).astype(np.float32)
+    # the three channels of the light differ, so do the image's
+    assert want.sum() > 0 and not np.allclose(want[..., 0], want[..., 1])
+    assert np.array_equal(bits(acc), bits(want)) and np.array_equal(screen, O.resolve_argb(want, spp))
+    for k in ("paths", "closest_rays", "shadow_rays", "tri_tests", "gate_passes", "diffuse_bounces", "mirror_bounces",
+              "glass_bounces", "fog_events"):
+        assert getattr(st, k) == getattr(ost, k), k
+    orgb, ocnt = O.trace_paths(tris, None, cam, light, p, px, py, smp)
+    assert np.array_equal(bits(rgb), bits(orgb)) and np.array_equal(cnt, ocnt)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(max_depth=3, rr_prob=0.35, diffuse_weight=0.8, glass_weight=1.05, ior_glass=1.33, ior_air=1.0003),
+    dict(max_depth=1, rr_prob=0.0, diffuse_weight=1.3, glass_weight=0.9, ior_glass=2.4, ior_air=1.0, fog_sigma_t=0.4, fog_albedo=0.5),
+    dict(max_depth=16, rr_prob=0.9, seed=0xFFFFFFFF, ior_glass=1.0, ior_air=1.5)])
+def test_parameters_off_their_defaults(api, O, pkg, kw):
+    # the #defines of definitions.h:43-55 as run-time parameters, away from the reference's values:
+    # depth limit, roulette, bounce weights, refraction indices (also air denser than glass), fog
+    abi = pkg.abi
+    tris = O.load_test_model(2)
+    sph = api.make_sphere(0.3, [-0.45, 0.7, -0.55, 1], [1, 0, 0])
+    W, H, spp = 80, 64, 32
+    cam, light = O.default_camera(W), O.default_light(True)
+    for rng_mode in (abi.RNG_COUNTER, abi.RNG_MINSTD_PATH):
+        p = O.default_params(W, H, rng_mode=rng_mode, flags=abi.FLAG_STATS, **kw)
+        sc = api.Scene(tris, sph)
+        acc = sc.render_accumulate(cam, light, p, 0, spp)
+        st = sc.stats()
+        sc.close()
+        _, ost = O.render_accumulate(tris, sph, cam, light, p, 0, spp, threads=8)
+        want = None
+        for b in range(0, spp, 16):
+            img, _ = O.render_accumulate(tris, sph, cam, light, p, b, 16, threads=8)
+            want = img.copy() if want is None else (want + img).astype(np.float32)
+        assert np.array_equal(bits(acc), bits(want)), (kw, rng_mode)
+        for k in ("paths", "closest_rays", "shadow_rays", "sphere_tests", "diffuse_bounces", "mirror_bounces", "glass_bounces",
+                  "fog_events"):
+            assert getattr(st, k) == getattr(ost, k), (k, kw)
+
+
 def test_render_sample_ranges_compose(api, O):
     # samples [0,64) in one call == [0,32) then [32,64) accumulated, bit for bit: the stream of a path
     # depends only on (pixel, sample index), and the sums of the work items (16 samples each) join the
