@@ -212,6 +212,10 @@ class Scene:
         """Pairs among pair_units() whose plane is normal to a coordinate axis."""
         return int(self._lib.mipt_scene_axis_pair_units(self._h))
 
+    def box_units(self):
+        """Groups of pair_units() that are faces of one parallelepiped and are filtered in its frame."""
+        return int(self._lib.mipt_scene_box_units(self._h))
+
     def stats(self):
         s = abi.MiptStats()
         _check(self._lib.mipt_get_stats(self._h, C.byref(s)))

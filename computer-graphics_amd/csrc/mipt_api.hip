@@ -85,6 +85,7 @@ struct MiptScene {
   ScanUnit* d_units = nullptr;
   uint32_t n_pair_units = 0;
   uint32_t n_axis_units = 0;
+  uint32_t n_box_units = 0;
   ShadeRec* d_shade = nullptr;
   SphereRec* d_spheres = nullptr;
   unsigned long long* d_stats = nullptr;
@@ -272,7 +273,8 @@ static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
 // up to MAX_BIG such triangles are tested one by one before the walk instead.
 constexpr size_t MAX_BIG = 64;
 static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>& tr, const std::vector<int>& ids,
-                             std::vector<ScanUnit>& units, uint32_t& n_pair_units, uint32_t& n_axis_units);
+                             std::vector<ScanUnit>& units, uint32_t& n_pair_units, uint32_t& n_axis_units,
+                             uint32_t& n_box_units);
 static int upload_scan_units(MiptScene* s, const std::vector<ScanUnit>& units);
 static int build_tree_scene(MiptScene* s, const MiptTriangle* tris, const std::vector<TriRec>& tr, size_t n_tris) {
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -331,7 +333,7 @@ static int build_tree_scene(MiptScene* s, const MiptTriangle* tris, const std::v
   s->d.n_big = (int)big.size();
   if (!big.empty()) {  // the candidate filter's units over the big list (walls come in coplanar pairs)
     std::vector<ScanUnit> units;
-    build_scan_units(tris, tr, big, units, s->n_pair_units, s->n_axis_units);
+    build_scan_units(tris, tr, big, units, s->n_pair_units, s->n_axis_units, s->n_box_units);
     const int rc = upload_scan_units(s, units);
     if (rc != MIPT_OK) return rc;
   }
@@ -440,32 +442,235 @@ static void make_single_unit(const TriRec& t, ScanUnit& u) {
   u.kA = t.kA; u.kB = t.kB;
 }
 
+// ---- box units (BoxUnit in mipt_device.hpp): coplanar pairs that are faces of one parallelepiped
+
+// The four corners of the parallelogram two triangles with a shared edge form, in cyclic order
+// r, s1, q, s2 (A = (r, s1, s2), B = (s1, s2, q)); false when they share no edge or q is not
+// s1 + s2 - r to 10^-6 of the size.
+struct QuadRef {
+  const float* c[4];
+  uint32_t bit_a, bit_b;  // chunk-relative mask bits of A and B
+  bool axis_form;         // the pair on its own would take the axis form of the filter
+  bool used;
+};
+static bool quad_of_pair(const MiptTriangle& A, const MiptTriangle& B, QuadRef& qd) {
+  const float* av[3] = {A.v0, A.v1, A.v2};
+  const float* bv[3] = {B.v0, B.v1, B.v2};
+  int a_of_b[3] = {-1, -1, -1}, n_shared = 0;
+  bool a_used[3] = {false, false, false};
+  for (int j = 0; j < 3; ++j)
+    for (int i = 0; i < 3; ++i)
+      if (!a_used[i] && a_of_b[j] < 0 && same_vertex(av[i], bv[j])) { a_of_b[j] = i; a_used[i] = true; ++n_shared; }
+  if (n_shared != 2) return false;
+  int ir = 0, jq = 0;
+  for (int i = 0; i < 3; ++i) if (!a_used[i]) ir = i;
+  for (int j = 0; j < 3; ++j) if (a_of_b[j] < 0) jq = j;
+  const float* r = av[ir];
+  const float* s1 = av[(ir + 1) % 3];
+  const float* s2 = av[(ir + 2) % 3];
+  const float* q = bv[jq];
+  double size = 0.0, dev = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    size = std::fmax(size, std::fmax(std::fabs((double)s1[k] - r[k]), std::fabs((double)s2[k] - r[k])));
+    dev = std::fmax(dev, std::fabs((double)q[k] - ((double)s1[k] + (double)s2[k] - (double)r[k])));
+  }
+  if (!(size > 0.0 && dev <= 1e-6 * size)) return false;
+  qd.c[0] = r; qd.c[1] = s1; qd.c[2] = q; qd.c[3] = s2;
+  qd.used = false;
+  return true;
+}
+
+static bool invert3(const double M[3][3], double inv[3][3], double& det) {
+  const double c00 = M[1][1] * M[2][2] - M[1][2] * M[2][1], c01 = M[1][2] * M[2][0] - M[1][0] * M[2][2],
+               c02 = M[1][0] * M[2][1] - M[1][1] * M[2][0];
+  det = M[0][0] * c00 + M[0][1] * c01 + M[0][2] * c02;
+  if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+  inv[0][0] = c00 / det; inv[1][0] = c01 / det; inv[2][0] = c02 / det;
+  inv[0][1] = (M[0][2] * M[2][1] - M[0][1] * M[2][2]) / det;
+  inv[1][1] = (M[0][0] * M[2][2] - M[0][2] * M[2][0]) / det;
+  inv[2][1] = (M[0][1] * M[2][0] - M[0][0] * M[2][1]) / det;
+  inv[0][2] = (M[0][1] * M[1][2] - M[0][2] * M[1][1]) / det;
+  inv[1][2] = (M[0][2] * M[1][0] - M[0][0] * M[1][2]) / det;
+  inv[2][2] = (M[0][0] * M[1][1] - M[0][1] * M[1][0]) / det;
+  return true;
+}
+
+// Tries to grow a box from quad `seed`: a corner r of it with its two neighbours a, b, and a third
+// edge c taken from another quad that meets the seed along an edge at r. Every unused quad whose
+// corners sit on the corners of one face of the parallelepiped (r; a - r, b - r, c - r) to 10^-6 of
+// the size joins. Three faces make a box, and so do two when one of them would otherwise need the
+// general (cross product) form of the filter: the vertical sides of a block whose base is no
+// parallelogram pair up around two opposite vertical edges.
+static bool make_box_unit(std::vector<QuadRef>& quads, size_t seed, BoxUnit& box, std::vector<size_t>& members) {
+  const QuadRef& Q0 = quads[seed];
+  for (int i0 = 0; i0 < 4; ++i0) {
+    const float* r = Q0.c[i0];
+    const float* a = Q0.c[(i0 + 1) % 4];
+    const float* b = Q0.c[(i0 + 3) % 4];
+    for (size_t j = 0; j < quads.size(); ++j) {
+      if (j == seed || quads[j].used) continue;
+      const QuadRef& Qj = quads[j];
+      const float* c = nullptr;
+      for (int i = 0; i < 4 && !c; ++i) {
+        if (!same_vertex(Qj.c[i], r)) continue;
+        const float* n1 = Qj.c[(i + 1) % 4];
+        const float* n2 = Qj.c[(i + 3) % 4];
+        const bool n1_shared = same_vertex(n1, a) || same_vertex(n1, b);
+        const bool n2_shared = same_vertex(n2, a) || same_vertex(n2, b);
+        if (n1_shared && !n2_shared) c = n2;
+        else if (n2_shared && !n1_shared) c = n1;
+      }
+      if (!c) continue;
+      // frame: columns A, B, C
+      double M[3][3], inv[3][3], vol;
+      for (int k = 0; k < 3; ++k) {
+        M[k][0] = (double)a[k] - r[k]; M[k][1] = (double)b[k] - r[k]; M[k][2] = (double)c[k] - r[k];
+      }
+      if (!invert3(M, inv, vol)) continue;
+      double edge = 0.0;
+      for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) edge = std::fmax(edge, std::fabs(M[k][l]));
+      if (!(std::fabs(vol) >= 1e-3 * edge * edge * edge)) continue;  // well shaped
+      // which unused quads are faces of this parallelepiped
+      struct Face { int quad; bool flip, a_is_lo; };
+      Face face[3][2];
+      for (int w = 0; w < 3; ++w) for (int sd = 0; sd < 2; ++sd) face[w][sd].quad = -1;
+      int n_faces = 0;
+      double emax = edge;
+      for (size_t m = 0; m < quads.size(); ++m) {
+        if (quads[m].used) continue;
+        const QuadRef& Qm = quads[m];
+        int fc[4][3];
+        bool ok = true;
+        for (int v = 0; v < 4 && ok; ++v) {
+          double x[3] = {(double)Qm.c[v][0] - r[0], (double)Qm.c[v][1] - r[1], (double)Qm.c[v][2] - r[2]};
+          double ideal[3] = {0, 0, 0};
+          for (int i = 0; i < 3; ++i) {
+            const double f = inv[i][0] * x[0] + inv[i][1] * x[1] + inv[i][2] * x[2];
+            const double fr = std::nearbyint(f);
+            if (!(fr == 0.0 || fr == 1.0)) { ok = false; break; }
+            fc[v][i] = (int)fr;
+            for (int k = 0; k < 3; ++k) ideal[k] += fr * M[k][i];
+          }
+          for (int k = 0; k < 3 && ok; ++k) if (!(std::fabs(ideal[k] - x[k]) <= 1e-6 * edge)) ok = false;
+        }
+        if (!ok) continue;
+        // one coordinate constant over the four corners, the other two running over the unit square
+        int w = -1;
+        for (int i = 0; i < 3; ++i)
+          if (fc[0][i] == fc[1][i] && fc[1][i] == fc[2][i] && fc[2][i] == fc[3][i]) { w = (w < 0) ? i : 3; }
+        if (w < 0 || w > 2) continue;
+        const int ip = (w + 1) % 3, iq = (w + 2) % 3;
+        // cyclic order r, s1, q, s2: opposite corners differ in both coordinates, neighbours in one
+        if (fc[0][ip] == fc[2][ip] || fc[0][iq] == fc[2][iq] || fc[1][ip] == fc[3][ip] || fc[1][iq] == fc[3][iq]) continue;
+        const int sd = fc[0][w];
+        if (face[w][sd].quad >= 0) continue;
+        Face F;
+        F.quad = (int)m;
+        // the pair's shared edge s1 - s2 is the diagonal; it must run (1,0) - (0,1) after the flip
+        F.flip = (fc[1][ip] + fc[1][iq]) != 1;
+        const int pr = F.flip ? 1 - fc[0][ip] : fc[0][ip];
+        F.a_is_lo = (pr == 0 && fc[0][iq] == 0);
+        if (!F.a_is_lo && !(pr == 1 && fc[0][iq] == 1)) continue;
+        face[w][sd] = F;
+        ++n_faces;
+        for (int u = 0; u < 4; ++u) for (int v = u + 1; v < 4; ++v) for (int k = 0; k < 3; ++k)
+          emax = std::fmax(emax, std::fabs((double)Qm.c[u][k] - (double)Qm.c[v][k]));
+      }
+      if (n_faces < 2) continue;
+      if (n_faces == 2) {
+        bool general = false;
+        for (int w = 0; w < 3; ++w) for (int sd = 0; sd < 2; ++sd)
+          if (face[w][sd].quad >= 0 && !quads[(size_t)face[w][sd].quad].axis_form) general = true;
+        if (!general) continue;
+      }
+      double vmax = 0.0;
+      for (int k = 0; k < 3; ++k) vmax = std::fmax(vmax, std::fabs((double)r[k]));
+      if (!(emax >= 9.094947e-13 && emax <= 1.0995116e12 && vmax + 3.0 * emax <= 1.0995116e12)) continue;
+      // the record
+      memset(&box, 0, sizeof box);
+      box.rx = r[0]; box.ry = r[1]; box.rz = r[2];
+      double R[3], rmax = 0.0, rmin = INFINITY;
+      for (int i = 0; i < 3; ++i) {
+        R[i] = 0.0;
+        for (int k = 0; k < 3; ++k) { box.m[3 * i + k] = (float)inv[i][k]; R[i] += std::fabs((double)box.m[3 * i + k]); }
+        R[i] *= 1.000001;
+        rmax = std::fmax(rmax, R[i]); rmin = std::fmin(rmin, R[i]);
+      }
+      const double eps = 5.9604644775390625e-08, av = std::fabs(vol);
+      const double kappa = rmax / rmin, lambda = std::fmax(1.0, emax * rmax);
+      if (!(kappa <= 64.0 && lambda <= 64.0)) continue;
+      const double up = 1.000001;
+      box.rmax = (float)(rmax * up);
+      box.c0 = (float)(0.0211 + 1e-5 * lambda);
+      box.k6 = (float)(2.0 * 12.0 * eps * kappa * up);
+      for (int w = 0; w < 3; ++w) {
+        box.kA[w] = (float)(std::fmax(0.001953125 * emax * emax / av, 0.001953125 * R[w]) * FILTER_TIGHT * 1.001);
+        const double kR = 3.0517578125e-05 * lambda * emax / (rmax * R[w] * av);
+        box.kh[w] = (float)((2.0 * kR + 8e-6 * lambda * kappa + 2.0 * 60.0 * eps * kappa) * up);
+        box.kT[w] = (float)((3.0517578125e-05 * lambda * emax * emax / (rmax * av) + 10.0 * eps) * 1.01);
+        box.rw[w] = (float)(R[w] * up);
+        if (!(std::isfinite(box.kA[w]) && std::isfinite(box.kh[w]) && std::isfinite(box.kT[w]) && box.kA[w] > 0.f)) { n_faces = 0; break; }
+        for (int sd = 0; sd < 2; ++sd) {
+          const Face& F = face[w][sd];
+          if (F.quad < 0) continue;
+          const QuadRef& Qm = quads[(size_t)F.quad];
+          const uint32_t lo = F.a_is_lo ? Qm.bit_a : Qm.bit_b, hi = F.a_is_lo ? Qm.bit_b : Qm.bit_a;
+          box.faces[w] |= (lo | (hi << 5) | (F.flip ? 0x400u : 0u) | 0x800u) << (12 * sd);
+        }
+      }
+      if (n_faces < 2) continue;
+      members.clear();
+      for (int w = 0; w < 3; ++w) for (int sd = 0; sd < 2; ++sd)
+        if (face[w][sd].quad >= 0) members.push_back((size_t)face[w][sd].quad);
+      return true;
+    }
+  }
+  return false;
+}
+
 // per chunk of 32 triangles: pairs (greedy over consecutive indices) first, then singles
 // `ids` lists the triangles to cover, ascending (all of them for a linear-scan scene, the big ones
 // of a tree scene); mask bit p of chunk c stands for triangle ids[32 c + p].
 static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>& tr, const std::vector<int>& ids,
-                             std::vector<ScanUnit>& units, uint32_t& n_pair_units, uint32_t& n_axis_units) {
+                             std::vector<ScanUnit>& units, uint32_t& n_pair_units, uint32_t& n_axis_units,
+                             uint32_t& n_box_units) {
   const size_t n = ids.size();
   const size_t n_chunks = (n + 31) / 32;
   units.assign(n_chunks * 32 + 1, ScanUnit{});
   n_pair_units = 0;
   n_axis_units = 0;
-  bool pairing = true;
+  n_box_units = 0;
+  bool pairing = true, boxing = true;
 #ifdef MIPT_DEV_SWITCHES
   const char* no_pairs = getenv("MIPT_NO_PAIRS");  // developer build only: every triangle its own unit
   pairing = !(no_pairs && no_pairs[0] == '1');
+  const char* no_boxes = getenv("MIPT_NO_BOXES");  // developer build only: no box units
+  boxing = !(no_boxes && no_boxes[0] == '1');
 #endif
   for (size_t c = 0; c < n_chunks; ++c) {
     const size_t lo = c * 32, hi = std::min(n, lo + 32);
+    struct PairEntry { ScanUnit u; bool axis_form; int quad; };
+    std::vector<PairEntry> pair_list;
+    std::vector<QuadRef> quads;
     std::vector<ScanUnit> axis_pairs, pairs, singles;
     for (size_t p = lo; p < hi;) {
       ScanUnit u;
       const int i = ids[p];
       if (pairing && p + 1 < hi && ids[p + 1] == i + 1 && std::isfinite(tr[i].kA) && std::isfinite(tr[i + 1].kA) &&
           make_pair_unit(tris[i], tris[i + 1], u)) {
-        const bool axis_form = u.meta == 0x80000000u;
+        PairEntry e;
+        e.axis_form = u.meta == 0x80000000u;
         u.meta = (uint32_t)(p - lo) | ((uint32_t)(p + 1 - lo) << 5);
-        (axis_form ? axis_pairs : pairs).push_back(u);
+        e.u = u;
+        e.quad = -1;
+        QuadRef qd;
+        if (boxing && quad_of_pair(tris[i], tris[i + 1], qd)) {
+          qd.bit_a = (uint32_t)(p - lo); qd.bit_b = (uint32_t)(p + 1 - lo);
+          qd.axis_form = e.axis_form;
+          e.quad = (int)quads.size();
+          quads.push_back(qd);
+        }
+        pair_list.push_back(e);
         p += 2;
       } else {
         make_single_unit(tr[i], u);
@@ -474,17 +679,38 @@ static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>
         p += 1;
       }
     }
+    // parallelograms that are faces of one parallelepiped leave the pair list for a box unit
+    std::vector<BoxUnit> boxes;
+    for (size_t qi = 0; qi < quads.size(); ++qi) {
+      if (quads[qi].used) continue;
+      BoxUnit box;
+      std::vector<size_t> members;
+      if (!make_box_unit(quads, qi, box, members)) continue;
+      for (size_t m : members) quads[m].used = true;
+      boxes.push_back(box);
+    }
+    size_t n_axis_here = 0;
+    for (const PairEntry& e : pair_list) {
+      if (e.axis_form) ++n_axis_here;
+      if (e.quad >= 0 && quads[(size_t)e.quad].used) continue;
+      (e.axis_form ? axis_pairs : pairs).push_back(e.u);
+    }
     size_t k = lo;
+    for (const BoxUnit& b : boxes) { memcpy(&units[k], &b, sizeof b); k += 2; }
     std::stable_sort(axis_pairs.begin(), axis_pairs.end(), [](const ScanUnit& x, const ScanUnit& y) {
       uint32_t ax, ay; memcpy(&ax, &x.e2z, 4); memcpy(&ay, &y.e2z, 4); return ax < ay; });
     for (const ScanUnit& u : axis_pairs) units[k++] = u;
     for (const ScanUnit& u : pairs) units[k++] = u;
     for (const ScanUnit& u : singles) units[k++] = u;
     const size_t all_pairs = axis_pairs.size() + pairs.size();
-    units[lo].meta |= ((uint32_t)axis_pairs.size() << 10) | ((uint32_t)all_pairs << 16) |
-                      ((uint32_t)(all_pairs + singles.size()) << 24);
-    n_pair_units += (uint32_t)all_pairs;
-    n_axis_units += (uint32_t)axis_pairs.size();
+    // the counts of the chunk (unit_mask); a box keeps its meta where a scan unit does
+    const uint32_t counts = ((uint32_t)axis_pairs.size() << 10) | ((uint32_t)all_pairs << 15) |
+                            ((uint32_t)(all_pairs + singles.size()) << 20) | ((uint32_t)boxes.size() << 26);
+    if (boxes.empty()) units[lo].meta |= counts;
+    else reinterpret_cast<BoxUnit*>(&units[lo])->meta = counts;
+    n_pair_units += (uint32_t)pair_list.size();
+    n_axis_units += (uint32_t)n_axis_here;
+    n_box_units += (uint32_t)boxes.size();
   }
 }
 
@@ -587,7 +813,7 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
   std::vector<ScanUnit> units;
   std::vector<int> all(n_tris);
   for (size_t i = 0; i < n_tris; ++i) all[i] = (int)i;
-  build_scan_units(tris, tr, all, units, s->n_pair_units, s->n_axis_units);
+  build_scan_units(tris, tr, all, units, s->n_pair_units, s->n_axis_units, s->n_box_units);
   return upload_scan_units(s, units);
 }
 
@@ -652,6 +878,7 @@ static inline unsigned batch_grid(size_t n_rays) {
 
 extern "C" int mipt_scene_pair_units(MiptScene* s) { return s ? (int)s->n_pair_units : 0; }
 extern "C" int mipt_scene_axis_pair_units(MiptScene* s) { return s ? (int)s->n_axis_units : 0; }
+extern "C" int mipt_scene_box_units(MiptScene* s) { return s ? (int)s->n_box_units : 0; }
 
 // Tree batches of SORT_MIN_RAYS rays or more: bin the rays by origin cell unless they come coherent.
 // On return b.order is null (walk the rays as they come) or b holds the batch in walking order and

@@ -75,7 +75,7 @@ struct __attribute__((aligned(64))) ScanUnit {
   float emax;        // pairs: largest |edge|oo of the two triangles (0 for single triangles)
   float qc, qu, qv;  // pairs: the second triangle in the frame of the first
   uint32_t meta;     // bits 0-4 / 5-9: mask bit of the first / second triangle; first record of a
-                     // chunk only: 10-15 axis-plane pairs, 16-23 all pairs, 24-31 units in this chunk
+                     // chunk only: the chunk's unit counts (see unit_mask)
 };
 // A pair whose plane is normal to coordinate axis k (f1, f2 and the far vertex have an exactly zero
 // k component: walls, floors, box tops) is stored first in its chunk and in another form, because
@@ -86,6 +86,51 @@ struct __attribute__((aligned(64))) ScanUnit {
 // |n| = |f1_i f2_j - f1_j f2_i|, so that with |det| = |n| |d_k| the bounds are those of the
 // general form. The evaluation has fewer roundings than the general one and stays inside the same
 // error budget (<= 10 eps S Dm / (|f1| |d_k|) against the 64 eps share of the filter).
+
+// BoxUnit: several coplanar pairs that are faces of ONE parallelepiped (the walls of the room, the
+// faces of a block) filtered in the parallelepiped's own frame. With corner r and edges A, B, C the
+// frame coordinates of a point x are m (x - r), m = (A B C)^-1 rounded from double; face "w = 0" /
+// "w = 1" of axis w is the unit square of the two other coordinates (p, q) = axes (w + 1, w + 2) mod 3
+// in the plane where coordinate w is 0 / 1, and its two triangles are the halves p + q <= 1 ("lo")
+// and p + q >= 1 ("hi") -- after p -> 1 - p when the face is split along its other diagonal. The ray
+// is mapped into the frame once (18 multiply-adds) and every face then costs a reciprocal per axis,
+// two multiply-adds for its plane hit and a handful of comparisons: no cross products at all.
+// A box takes two consecutive ScanUnit slots at the head of its chunk; `meta` sits where
+// ScanUnit::meta does. faces[w]: bits 0-11 the face w = 0, bits 12-23 the face w = 1, each:
+// mask bit of the lo triangle (5 bits), of the hi triangle (5), flip p (1), face present (1).
+// Error model (every bound below is folded into the per-axis factors on the host, make_box_unit):
+//   * Frame coordinates are sums of three products with |m| rows of 1-norm R_i, so o' and d' are
+//     within 6 eps R_i |s|oo and 6 eps R_i |d|oo of their exact values. With W = |d'_w|,
+//     G = R_w |d|oo / W >= 1 (how grazing the ray is for axis w) and Z = 1 + rmax |s|oo (which bounds
+//     1 + every |o'_i|), the computed (p, q) of a face of axis w are within
+//     eps kappa Z G (30 + 6 G) of the exact plane hit, kappa = max R_i / min R_i.
+//   * The reference's own barycentrics of a triangle of that face are, for a ray that is `well`
+//     (W >= |d|oo kA_w: its determinant |d . (e1 x e2)| = W vol is at least
+//     2^12 eps 8 |d|oo emax^2, as for pair units), within 0.01 + 2^-15 lambda Z G emax / (rmax R_w vol)
+//     of the exact ones (tri_candidate's bound with |o - v0|oo <= |s|oo + 3 emax), lambda =
+//     max(1, emax rmax); vertices may sit off the ideal corners by 10^-6 emax, which moves the exact
+//     hit by at most 4 10^-6 lambda kappa G in frame units.
+//   * The reference accepts only if x1, x2 >= 0 and x1 + x2 <= 1.001 as it computes them, hence
+//     only if all three exact barycentrics are >= -(0.001 + 2 m), m = its error; whichever way it
+//     labels the vertices, the three are (p, q, 1 - p - q) for lo and (1 - p, 1 - q, p + q - 1) for hi.
+//     delta = 0.001 + 2 m + 2 f (f = the filter's error) therefore decides every comparison.
+//   * t: the ray parameter is the same number in every frame; dt covers the reference's
+//     numerator noise (2^-15 lambda Z emax^2 / (rmax vol W)) and the filter's own (10 eps Z / W).
+struct __attribute__((aligned(64))) BoxUnit {
+  float rx, ry, rz;
+  float m[9];     // rows of (A B C)^-1
+  float rmax;     // largest R_i, rounded up
+  float c0;       // constant part of delta
+  float k6;       // 2 * 6 eps kappa, with a safety factor
+  uint32_t meta;  // chunk counts when this is the chunk's first record (see unit_mask)
+  float kA[3];    // `well` thresholds per axis
+  float kh[3];    // first-order coefficient of delta per axis
+  float kT[3];    // coefficient of dt per axis
+  float rw[3];    // R_w
+  uint32_t faces[3];
+  uint32_t pad;
+};
+static_assert(sizeof(BoxUnit) == 128, "a box takes two scan-unit slots");
 
 struct BvhNode;
 
@@ -486,15 +531,70 @@ __device__ __forceinline__ void axis_pair_candidates(UP U, float sk, float si, f
   if (!(well & outB)) mask |= 1u << ((meta >> 5) & 31u);
 }
 
+// The candidate filter over a box unit (see BoxUnit).
+template <typename BP>
+__device__ __forceinline__ void box_candidates(BP B, V4 o, V4 d, float Dm, uint32_t& mask) {
+#pragma clang fp contract(fast)
+  const float sx = o.x - B->rx, sy = o.y - B->ry, sz = o.z - B->rz;
+  const float S = fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz));
+  const float Z = S * B->rmax + 1.0f;
+  float oc[3], dc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    oc[i] = B->m[3 * i] * sx + B->m[3 * i + 1] * sy + B->m[3 * i + 2] * sz;
+    dc[i] = B->m[3 * i] * d.x + B->m[3 * i + 1] * d.y + B->m[3 * i + 2] * d.z;
+  }
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const uint32_t fw = B->faces[w];  // wave-uniform
+    if (!(fw & 0x800800u)) continue;
+    const int ip = (w + 1) % 3, iq = (w + 2) % 3;
+    const float dw = dc[w];
+    const bool well = fabsf(dw) >= Dm * B->kA[w] + 1e-35f;
+    const float inv = __builtin_amdgcn_rcpf(dw);
+    const float ainv = fabsf(inv);
+    const float G = (Dm * B->rw[w]) * ainv;
+    const float h = G * B->k6 + B->kh[w];
+    const float delta = (Z * G) * h + B->c0;
+    const float dt = (Z * ainv) * B->kT[w] + 1e-30f;
+    const float one_p = 1.0f + delta, one_m = 1.0f - delta;
+    const float t0 = -(oc[w] * inv);
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const uint32_t f = (fw >> (12 * side)) & 0xFFFu;
+      if (!(f & 0x800u)) continue;
+      const float t = side ? t0 + inv : t0;
+      const float p0 = t * dc[ip] + oc[ip], q = t * dc[iq] + oc[iq];
+      const float p = (f & 0x400u) ? 1.0f - p0 : p0;
+      const float sig = p + q;
+      const bool behind = t < -dt;
+      const bool lo_out = (p < -delta) | (q < -delta) | (sig > one_p) | behind;
+      const bool hi_out = (p > one_p) | (q > one_p) | (sig < one_m) | behind;
+      if (!(well & lo_out)) mask |= 1u << (f & 31u);
+      if (!(well & hi_out)) mask |= 1u << ((f >> 5) & 31u);
+    }
+  }
+}
+
 // Phase 1 over one chunk of scan units (records [0, n_units) at `chunk`, pairs first): the mask of
 // the chunk's triangles the reference could accept. Unrolled so that the scalar loads of the next
 // record overlap the arithmetic of this one (rolled, every unit waits out its own load: -9 %).
 __device__ __forceinline__ uint32_t unit_mask(const ScanUnit* chunk, V4 o, V4 d, float Dm) {
   const ScanUnit MIPT_CONST* units = as_constant(chunk);
-  const uint32_t counts = units[0].meta >> 16;
-  const int n_pairs = (int)(counts & 0xFFu), n_units = (int)(counts >> 8);
-  const int n_axis = (int)((units[0].meta >> 10) & 0x3Fu);
+  // counts in the chunk's first record (a box keeps its meta where a scan unit does): bits 10-14
+  // axis-plane pairs, 15-19 all pairs, 20-25 pairs + singles, 26-28 boxes (two slots each, first)
+  const uint32_t m0 = units[0].meta;
+  const int n_box = (int)((m0 >> 26) & 7u);
+  const int n_axis = (int)((m0 >> 10) & 31u), n_pairs = (int)((m0 >> 15) & 31u), n_units = (int)((m0 >> 20) & 63u);
   uint32_t mask = 0;
+  {
+    const BoxUnit MIPT_CONST* boxes = reinterpret_cast<const BoxUnit MIPT_CONST*>(units);
+    // (rolled, fields read where they are used: copying the record into registers up front costs
+    // a dozen more spilled scalar registers than the waits it saves)
+#pragma unroll 1
+    for (int k = 0; k < n_box; ++k) box_candidates(boxes + k, o, d, Dm, mask);
+    units += 2 * n_box;
+  }
   // axis-plane pairs come sorted by axis; the ray is permuted once per run of equal axes.
   // (Rolled: unrolled by 2 or 4 the kernel spills registers; requesting the next record before
   // this one is evaluated costs more in register copies than the wait it hides.)

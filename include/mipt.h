@@ -217,6 +217,11 @@ int mipt_scene_pair_units(MiptScene* scene);
  * tops): the filter solves their ray/plane system without cross products. No counterpart in the
  * reference either. */
 int mipt_scene_axis_pair_units(MiptScene* scene);
+/* ... and how many groups of at least three such pairs are the faces of one parallelepiped (the
+ * room's five walls, the five faces of a block, TestModelH.h:87-106, 108-139, 141-172): the filter maps the ray
+ * into the parallelepiped's frame once and tests all its faces there. The pairs inside such a
+ * group still count in mipt_scene_pair_units. No counterpart in the reference. */
+int mipt_scene_box_units(MiptScene* scene);
 void mipt_scene_destroy(MiptScene* scene);
 
 /* Batch closestIntersection (intersections.cpp:6-55). Host pointers.

@@ -537,15 +537,93 @@ def quad_scene(O, dtype, n_quads, seed, axis_planes=False):
 
 def test_cornell_walls_are_filtered_as_pairs(api, O):
     # GlassCube: 5 walls, 5 faces of the block, the mirror = 11 pairs of 22 triangles; the walls
-    # and the block's top lie in axis planes
+    # and the block's top lie in axis planes. The five walls are faces of one cube; the block's base
+    # is no parallelogram, so its four sides make two two-face boxes around opposite vertical edges.
     sc = api.Scene(O.load_test_model(2))
     assert sc.pair_units() == 11
     assert 6 <= sc.axis_pair_units() <= 7
+    assert sc.box_units() == 3
     sc.close()
     sc = api.Scene(O.load_test_model(0))
     assert sc.pair_units() >= 13   # 5 walls + 4 side faces of each block (their tops are no parallelograms)
     assert sc.axis_pair_units() >= 5
+    assert sc.box_units() == 5
     sc.close()
+
+
+def box_scene(O, dtype, n_boxes, seed, sizes=(-1.3, 0.0)):
+    """Parallelepipeds whose faces are pairs of consecutive triangles: turned and sheared frames,
+    sizes over a decade, faces missing at random, either diagonal, any vertex labelling, either order
+    of a face's two triangles; every fourth box has one corner moved (within and beyond the tolerance
+    of the filter's box units, and far beyond it). 12 triangles per whole box, so boxes also straddle
+    the chunks of 32 triangles the filter works in."""
+    import bigscenes
+    rng = np.random.default_rng(seed)
+    v0s, v1s, v2s = [], [], []
+    for k in range(n_boxes):
+        size = 10 ** rng.uniform(*sizes)
+        r = rng.uniform(-0.8, 0.8, 3)
+        if k % 3 == 0:      # axis-aligned
+            F = np.diag(rng.uniform(0.3, 1.0, 3) * rng.choice([-1.0, 1.0], 3))
+        else:               # turned, and sheared for every other one
+            F, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            F = F * rng.uniform(0.3, 1.0, 3)
+            if k % 2 == 0:
+                F[:, 2] += F[:, 0] * rng.uniform(-0.5, 0.5)
+        F = F * size
+        corner = {}
+        for i in (0, 1):
+            for j in (0, 1):
+                for l in (0, 1):
+                    corner[(i, j, l)] = np.float32(r + F[:, 0] * i + F[:, 1] * j + F[:, 2] * l)
+        if k % 4 == 3:
+            corner[(1, 1, 1)] = np.float32(corner[(1, 1, 1)] + F[:, 0] * 10 ** rng.choice([-7.5, -5.0, -2.0]))
+        for w in range(3):
+            for side in (0, 1):
+                if rng.uniform() < 0.25:
+                    continue
+                ip, iq = (w + 1) % 3, (w + 2) % 3
+                def at(p, q):
+                    c = [0, 0, 0]
+                    c[w], c[ip], c[iq] = side, p, q
+                    return corner[tuple(c)]
+                P = [at(0, 0), at(1, 0), at(1, 1), at(0, 1)]
+                if rng.uniform() < 0.5:
+                    P = P[1:] + P[:1]        # the other diagonal
+                ta, tb = [P[0], P[1], P[2]], [P[0], P[2], P[3]]
+                if rng.uniform() < 0.5:
+                    ta, tb = tb, ta
+                for t in (ta, tb):
+                    o = rng.permutation(3)
+                    v0s.append(t[o[0]]); v1s.append(t[o[1]]); v2s.append(t[o[2]])
+    n = len(v0s)
+    color = rng.uniform(0.2, 0.9, (n, 3)).astype(np.float32)
+    return bigscenes._finish(dtype, np.array(v0s), np.array(v1s), np.array(v2s), color, np.zeros(n, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("seed,sizes", [(11, (-1.3, 0.0)), (12, (-1.3, 0.0)), (13, (-3.0, -1.0))])
+def test_box_units_equal_literal_scan(api, O, pkg, seed, sizes):
+    # faces of parallelepipeds are filtered in the parallelepiped's frame (box units); the scan's
+    # results must stay those of the literal scan and of the oracle
+    tris = box_scene(O, pkg.abi.TRIANGLE_DTYPE, 24, seed, sizes)
+    assert len(tris) < 256
+    sc = api.Scene(tris)
+    assert not sc.bvh_info()[0]
+    if sizes[0] > -2:
+        assert sc.box_units() >= 12
+    _, _, closest_bad, any_bad = sc.selfcheck(1 << 26, seed=seed)
+    assert (closest_bad, any_bad) == (0, 0)
+    o, d = raygen.surface_rays(tris, 1 << 14, seed=seed)
+    idx, t, pos = sc.closest_hit(o, d)
+    occ = sc.any_hit(o, d, np.full(len(o), 0.7, dtype=np.float32))
+    sc.close()
+    oidx, ot, opos = O.closest_hit(tris, None, o, d)
+    assert np.array_equal(idx, oidx)
+    assert np.array_equal(bits(t[idx >= 0]), bits(ot[oidx >= 0]))
+    assert np.array_equal(occ, O.any_hit(tris, o, d, np.full(len(o), 0.7, dtype=np.float32)))
+    # rays in the faces' planes, along their edges, with zero, huge and tiny directions
+    o, d = raygen.degenerate_rays(tris, 4096, seed=seed)
+    check_closest(api, O, tris, None, o, d)
 
 
 @pytest.mark.parametrize("seed", [4, 5])
