@@ -604,18 +604,18 @@ static bool make_box_unit(std::vector<QuadRef>& quads, size_t seed, BoxUnit& box
       box.c0 = (float)(0.0211 + 1e-5 * lambda);
       box.k6 = (float)(2.0 * 12.0 * eps * kappa * up);
       for (int w = 0; w < 3; ++w) {
-        box.kA[w] = (float)(std::fmax(0.001953125 * emax * emax / av, 0.001953125 * R[w]) * FILTER_TIGHT * 1.001);
+        box.ax[w].kA = (float)(std::fmax(0.001953125 * emax * emax / av, 0.001953125 * R[w]) * FILTER_TIGHT * 1.001);
         const double kR = 3.0517578125e-05 * lambda * emax / (rmax * R[w] * av);
-        box.kh[w] = (float)((2.0 * kR + 8e-6 * lambda * kappa + 2.0 * 60.0 * eps * kappa) * up);
-        box.kT[w] = (float)((3.0517578125e-05 * lambda * emax * emax / (rmax * av) + 10.0 * eps) * 1.01);
-        box.rw[w] = (float)(R[w] * up);
-        if (!(std::isfinite(box.kA[w]) && std::isfinite(box.kh[w]) && std::isfinite(box.kT[w]) && box.kA[w] > 0.f)) { n_faces = 0; break; }
+        box.ax[w].kh = (float)((2.0 * kR + 8e-6 * lambda * kappa + 2.0 * 60.0 * eps * kappa) * up);
+        box.ax[w].kT = (float)((3.0517578125e-05 * lambda * emax * emax / (rmax * av) + 10.0 * eps) * 1.01);
+        box.ax[w].rw = (float)(R[w] * up);
+        if (!(std::isfinite(box.ax[w].kA) && std::isfinite(box.ax[w].kh) && std::isfinite(box.ax[w].kT) && box.ax[w].kA > 0.f)) { n_faces = 0; break; }
         for (int sd = 0; sd < 2; ++sd) {
           const Face& F = face[w][sd];
           if (F.quad < 0) continue;
           const QuadRef& Qm = quads[(size_t)F.quad];
           const uint32_t lo = F.a_is_lo ? Qm.bit_a : Qm.bit_b, hi = F.a_is_lo ? Qm.bit_b : Qm.bit_a;
-          box.faces[w] |= (lo | (hi << 5) | (F.flip ? 0x400u : 0u) | 0x800u) << (12 * sd);
+          box.ax[w].faces |= (lo | (hi << 5) | (F.flip ? 0x400u : 0u) | 0x800u) << (12 * sd);
         }
       }
       if (n_faces < 2) continue;

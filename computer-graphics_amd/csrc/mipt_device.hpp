@@ -96,7 +96,7 @@ struct __attribute__((aligned(64))) ScanUnit {
 // is mapped into the frame once (18 multiply-adds) and every face then costs a reciprocal per axis,
 // two multiply-adds for its plane hit and a handful of comparisons: no cross products at all.
 // A box takes two consecutive ScanUnit slots at the head of its chunk; `meta` sits where
-// ScanUnit::meta does. faces[w]: bits 0-11 the face w = 0, bits 12-23 the face w = 1, each:
+// ScanUnit::meta does. ax[w].faces: bits 0-11 the face w = 0, bits 12-23 the face w = 1, each:
 // mask bit of the lo triangle (5 bits), of the hi triangle (5), flip p (1), face present (1).
 // Error model (every bound below is folded into the per-axis factors on the host, make_box_unit):
 //   * Frame coordinates are sums of three products with |m| rows of 1-norm R_i, so o' and d' are
@@ -123,11 +123,13 @@ struct __attribute__((aligned(64))) BoxUnit {
   float c0;       // constant part of delta
   float k6;       // 2 * 6 eps kappa, with a safety factor
   uint32_t meta;  // chunk counts when this is the chunk's first record (see unit_mask)
-  float kA[3];    // `well` thresholds per axis
-  float kh[3];    // first-order coefficient of delta per axis
-  float kT[3];    // coefficient of dt per axis
-  float rw[3];    // R_w
-  uint32_t faces[3];
+  struct Axis {      // what one axis needs, side by side (one scalar load)
+    float kA;        // `well` threshold
+    float kh;        // first-order coefficient of delta
+    float kT;        // coefficient of dt
+    float rw;        // R_w
+    uint32_t faces;  // the two faces of this axis
+  } ax[3];
   uint32_t pad;
 };
 static_assert(sizeof(BoxUnit) == 128, "a box takes two scan-unit slots");
@@ -546,17 +548,17 @@ __device__ __forceinline__ void box_candidates(BP B, V4 o, V4 d, float Dm, uint3
   }
 #pragma unroll
   for (int w = 0; w < 3; ++w) {
-    const uint32_t fw = B->faces[w];  // wave-uniform
+    const uint32_t fw = B->ax[w].faces;  // wave-uniform
     if (!(fw & 0x800800u)) continue;
     const int ip = (w + 1) % 3, iq = (w + 2) % 3;
     const float dw = dc[w];
-    const bool well = fabsf(dw) >= Dm * B->kA[w] + 1e-35f;
+    const bool well = fabsf(dw) >= Dm * B->ax[w].kA + 1e-35f;
     const float inv = __builtin_amdgcn_rcpf(dw);
     const float ainv = fabsf(inv);
-    const float G = (Dm * B->rw[w]) * ainv;
-    const float h = G * B->k6 + B->kh[w];
+    const float G = (Dm * B->ax[w].rw) * ainv;
+    const float h = G * B->k6 + B->ax[w].kh;
     const float delta = (Z * G) * h + B->c0;
-    const float dt = (Z * ainv) * B->kT[w] + 1e-30f;
+    const float dt = (Z * ainv) * B->ax[w].kT + 1e-30f;
     const float one_p = 1.0f + delta, one_m = 1.0f - delta;
     const float t0 = -(oc[w] * inv);
 #pragma unroll
