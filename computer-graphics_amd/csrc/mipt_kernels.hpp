@@ -160,8 +160,14 @@ __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d
     prof.count(PF_N_GE3, __popc(mask) >= 3 ? 1u : 0u);
     prof.count(PF_N_GE4, __popc(mask) >= 4 ? 1u : 0u);
     prof.count(PF_N_GE6, __popc(mask) >= 6 ? 1u : 0u);
-    while (__any(mask != 0)) {
+    // (a do-while: as `while (__any(...))` the compiler also copied the state at the loop's head)
+    if (__any(mask != 0)) do {
       prof.count_wave(PF_N_ROUNDS);
+      // The scan state passes through an empty asm statement at the head of every round: without
+      // it the compiler keeps two copies of the six state registers across the divergent test
+      // and moves them back and forth at every join (31 moves per round, 3 with it and the
+      // do-while: +4 % paths/s).
+      asm volatile("" : "+v"(h.lim), "+v"(h.lim_lo), "+v"(h.lim_hi), "+v"(h.idx), "+v"(h.by), "+v"(h.bz), "+v"(mask));
       if (mask != 0) {
         const int i = base + __ffs((int)mask) - 1;
         mask &= mask - 1u;
@@ -171,7 +177,7 @@ __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d
         // existsIntersection is an OR: once occluded (lim = -1) no later test can change anything
         if (shadow && h.lim < 0.f) mask = 0;
       }
-    }
+    } while (__any(mask != 0));
     prof.mark(PF_PHASE2);
   }
 }
