@@ -537,7 +537,9 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   // path state
   V4 o = {0, 0, 0, 0}, d = {0, 0, 0, 0};
   Rng rng = {1u, 0u};
-  int depth = 0, sp = 0;
+  // the path's depth (bits 8..) and the height of its vertex stack (bits 0-7) share a register: one
+  // register more and the kernel spills at five waves per SIMD
+  uint32_t ds = 0;
   bool shadow = false, fresh = true;
   float shadow_max = 0.f;
   // Completion state: which stack buffer the running path writes (cur), which sum context its item
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       d.z = (a.M[2] * dvx + a.M[6] * dvy) + (a.M[10] * dvz + a.M[14] * dvw);
       d.w = (a.M[3] * dvx + a.M[7] * dvy) + (a.M[11] * dvz + a.M[15] * dvw);
       o = {a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], a.cam_pos[3]};
-      depth = 0; sp = 0; shadow = false; fresh = false;
+      ds = 0; shadow = false; fresh = false;
       if (STATS || LIST) st[ST_PATHS]++;
     }
 
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
         bool need_sc = false, scatter = false;
         float sc_phi = 0.f, sc_r = 0.f, sc_y = 0.f;
         V3 Nt = {sh.ntx, sh.nty, sh.ntz}, Nb = {sh.nbx, sh.nby, sh.nbz};
-        const bool terminal = depth >= P.max_depth || rng_next<RNG_MODE>(rng) <= P.rr_prob;  // :80
+        const bool terminal = ds >= ((uint32_t)P.max_depth << 8) || rng_next<RNG_MODE>(rng) <= P.rr_prob;  // :80
         prof.mark(PF_HIT);
         if (terminal) {
           // pathtracer.cpp:81-93 + directLight (light.cpp:13-31). Only what the shadow ray needs
@@ -795,8 +797,8 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           sc_r = sqrtf(s2 < 0.f ? 0.f : s2);
           sc_phi = 6.28318530718f * u2;
           need_sc = true; scatter = true;
-          tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + sp)) * BLOCK + tid] = (TagT)TAG_FOG;
-          sp++; depth++;
+          tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + (ds & 0xFFu))) * BLOCK + tid] = (TagT)TAG_FOG;
+          ds += 0x101u;  // sp++, depth++
           prof.mark(PF_SCATTER);
         } else {
           o = pos;  // pathtracer.cpp:100
@@ -812,19 +814,19 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
             sc_r = sqrtf(1.0f - sc_y * sc_y);
             sc_phi = (float)((2 * 3.14) * (double)ub);
             need_sc = true;
-            tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + sp)) * BLOCK + tid] = (TagT)h.idx;
+            tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + (ds & 0xFFu))) * BLOCK + tid] = (TagT)h.idx;
             if (sphere_hit) {
-              float* q = sph_n + ((size_t)sp * BLOCK + tid) * 4;
+              float* q = sph_n + ((size_t)(ds & 0xFFu) * BLOCK + tid) * 4;
               q[0] = nrm.x; q[1] = nrm.y; q[2] = nrm.z; q[3] = nrm.w;
             }
-            sp++; depth++;
+            ds += 0x101u;
             prof.mark(PF_DIFFUSE);
           } else if (mat == MIPT_MAT_MIRROR) {
             // bounceMirror (pathtracer.cpp:21-27); weight 1, nothing to unwind
             if (STATS) st[ST_MIRROR]++;
             const float ct = dot4(nrm, d) * -1.0f;
             nd = add4(d, scale4(nrm, ct * 2.0f)); renorm = true;
-            depth++;
+            ds += 0x100u;  // depth++
             prof.mark(PF_MIRROR);
           } else if (mat == MIPT_MAT_GLASS) {
             // bounceGlass (pathtracer.cpp:29-63)
@@ -847,15 +849,15 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
               nd = add4(d, scale4(n, cost1 * 2.0f));
             }
             renorm = true;
-            tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + sp)) * BLOCK + tid] = (TagT)TAG_GLASS;
-            sp++; depth++;
+            tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + (ds & 0xFFu))) * BLOCK + tid] = (TagT)TAG_GLASS;
+            ds += 0x101u;
             prof.mark(PF_GLASS);
           } else if (mat == MIPT_MAT_SPECULAR) {
             // bounceSpecular (pathtracer.cpp:65-70); weight 1
             if (STATS) st[ST_SPECULAR]++;
             const float k2 = dot4(d, nrm) * 2.f;
             nd = sub4(d, scale4(nrm, k2)); renorm = true;
-            depth++;
+            ds += 0x100u;
           } else {
             path_done = true;  // no branch of pathtracer.cpp:103-110 taken: colour stays 0
           }
@@ -903,7 +905,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
     if (defer) {
       flush = __any(pend && path_done && (want_job || (item_end && other_ctx))) || final_round;
     } else {
-      if (want_job) js = JS_PEND | ((uint32_t)sp << 8);  // one buffer, one context: all other bits stay 0
+      if (want_job) js = JS_PEND | ((ds & 0xFFu) << 8);  // one buffer, one context: all other bits stay 0
       flush = __any((js & JS_PEND) != 0);
     }
     prof.count_wave(PF_N_ITERS);
@@ -971,7 +973,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       }
     }
     if (defer && want_job)  // the path's buffers become the job's; the next path writes the other pair
-      js = ((js & (JS_CUR | JS_CTX)) ^ JS_CUR) | JS_PEND | ((js & JS_CTX) ? JS_JCTX : 0u) | ((uint32_t)sp << 8);
+      js = ((js & (JS_CUR | JS_CTX)) ^ JS_CUR) | JS_PEND | ((js & JS_CTX) ? JS_JCTX : 0u) | ((ds & 0xFFu) << 8);
     if (path_done) {
       s++;
       fresh = true;
