@@ -405,8 +405,9 @@ struct HitAcc {
 // exhaustively on the GPU by mipt_debug_selfcheck). Anything else (zero, subnormal, huge, inf,
 // NaN) takes the IEEE division. r0 is the caller's estimate v_rcp_f32(b).
 __device__ __forceinline__ float rcp_exact(float b, float r0) {
-  const float ab = fabsf(b);
-  if (ab >= 7.888609052210118e-31f && ab <= 1.2676506002282294e30f) {
+  // 2^-100 <= |b| <= 2^100 as one unsigned comparison of the bit pattern (a NaN lands outside):
+  // two float comparisons cost two scalar moves for their constants and a scalar OR on top
+  if ((__float_as_uint(b) & 0x7FFFFFFFu) - 0x0D800000u <= 0x64000000u) {
     float e = __builtin_fmaf(-b, r0, 1.0f);
     float r = __builtin_fmaf(e, r0, r0);
     e = __builtin_fmaf(-b, r, 1.0f);
@@ -639,10 +640,12 @@ __device__ __forceinline__ uint32_t unit_mask(const ScanUnit* chunk, V4 o, V4 d,
 // stored bits, ~20 fewer instructions per test.
 // T is a pointer to the record: through the constant address space when every lane tests the same
 // triangle (scalar loads), or to a lane-private copy when each lane tests its own candidate.
+// occluded: optional, a word cleared when a shadow ray is accepted (the two-phase scan's list of
+// candidates still to test: existsIntersection is an OR, nothing later can change the answer).
 template <bool STATS, bool FAST, typename TP>
 __device__ __forceinline__ void tri_test(TP T, int i, float ox, float oy, float oz, float px, float py,
                                          float pz, bool shadow, HitAcc& h, uint32_t& n_tests,
-                                         uint32_t& n_gate) {
+                                         uint32_t& n_gate, uint32_t* occluded = nullptr) {
   // existsIntersection leaves its loop at the first accepted triangle (:79); the lane keeps
   // scanning here (its gate can no longer pass), so those iterations are not counted as tests
   if (STATS) n_tests += (shadow && h.idx) ? 0u : 1u;
@@ -697,6 +700,7 @@ __device__ __forceinline__ void tri_test(TP T, int i, float ox, float oy, float 
       if (shadow) {
         h.set_lim(-1.0f);  // `break` (:79): no later triangle can pass t >= 0 && t <= -1
         h.idx = 1;
+        if (occluded) *occluded = 0u;
       } else {
         h.set_lim(fabsf(x0));  // :28
         h.idx = i;

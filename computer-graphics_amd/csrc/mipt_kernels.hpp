@@ -173,9 +173,8 @@ __device__ __forceinline__ void scan_triangles(const DeviceScene& sc, V4 o, V4 d
         mask &= mask - 1u;
         // each lane fetches ITS candidate record (from the caller's table: global memory, or LDS)
         const TriRec T = lane_tris[i];
-        tri_test<false, true>(&T, i, o.x, o.y, o.z, px, py, pz, shadow, h, n_tests, n_gate);
-        // existsIntersection is an OR: once occluded (lim = -1) no later test can change anything
-        if (shadow && h.lim < 0.f) mask = 0;
+        // existsIntersection is an OR: an accepted shadow ray clears the lane's mask
+        tri_test<false, true>(&T, i, o.x, o.y, o.z, px, py, pz, shadow, h, n_tests, n_gate, &mask);
       }
     } while (__any(mask != 0));
     prof.mark(PF_PHASE2);
