@@ -484,6 +484,22 @@ __global__ __launch_bounds__(BLOCK) MIPT_BATCH_OCC void k_bvh_batch(DeviceScene 
   __attribute__((amdgpu_waves_per_eu(KIND == SCENE_BVH ? MIPT_TREE_WAVES_PER_EU : MIPT_WAVES_PER_EU, \
                                      KIND == SCENE_BVH ? MIPT_TREE_WAVES_PER_EU : MIPT_WAVES_PER_EU)))
 
+// The kernel's argument block, read where a value is needed instead of being held in scalar
+// registers from the kernel's entry on: the path kernel's loop is short of scalar registers (23 were
+// spilled to lanes of a vector register and constants were re-made before every use), and the camera,
+// the light, the glass constants, the queue's geometry and the weights of the completion are each
+// needed in ONE branch of it. The empty asm statement hides the address from the compiler, which
+// would otherwise hoist the loads to the entry again. PathArgs is the kernel's only argument, so it
+// sits at offset 0 of the argument segment.
+__device__ __forceinline__ const PathArgs MIPT_CONST* late_args() {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  const PathArgs MIPT_CONST* k = (const PathArgs MIPT_CONST*)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma clang diagnostic pop
+  asm volatile("" : "+s"(k));
+  return k;
+}
+
 template <int RNG_MODE, bool STATS, bool LIST, int KIND>
 __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a) {
   extern __shared__ uint32_t lds_stack[];  // vertex stack(s) of tags, sphere normals, record tables
@@ -591,19 +607,21 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       const unsigned long long need = __ballot(!have);
       if (need && !drained) {
         if (res_next == res_end) {
+          const PathArgs MIPT_CONST* kq = late_args();  // the queue's geometry: once per 64 items
           uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(a.queue, 64u);
+          if (lane == 0) base = atomicAdd(kq->queue, 64u);
           base = __builtin_amdgcn_readfirstlane(base);
-          if (base >= a.n_items) {
+          if (base >= kq->n_items) {
             drained = true;
           } else {
+            const uint32_t n_slots = kq->n_slots, tiles_x = kq->tiles_x;
             res_next = base;
             res_end = base + 64u;  // n_items is a multiple of 64: a batch is one tile of one sample block
             res_base = base;
-            res_sb = base / a.n_slots;
-            const uint32_t tile = (base - res_sb * a.n_slots) >> 6;
-            res_ty = tile / a.tiles_x;
-            res_tx = tile - res_ty * a.tiles_x;
+            res_sb = base / n_slots;
+            const uint32_t tile = (base - res_sb * n_slots) >> 6;
+            res_ty = tile / tiles_x;
+            res_tx = tile - res_ty * tiles_x;
           }
         }
         if (!drained) {
@@ -658,13 +676,16 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       const float u2 = rng_next<RNG_MODE>(rng);
       const float dvx = (float)((double)(x - W / 2) + (double)(u1 * 2.0f - 1.0f) * 0.1);
       const float dvy = (float)((double)(y - H / 2) + (double)(u2 * 2.0f - 1.0f) * 0.1);
-      const float dvz = a.focal, dvw = 0.0f;
+      const PathArgs MIPT_CONST* ka = late_args();  // the camera: needed only where a path begins
+      const float MIPT_CONST* M = ka->M;
+      const float MIPT_CONST* cam_pos = ka->cam_pos;
+      const float dvz = ka->focal, dvw = 0.0f;
       // mat4 * vec4 (type_mat4x4.inl:641-652): (m0*v0 + m1*v1) + (m2*v2 + m3*v3)
-      d.x = (a.M[0] * dvx + a.M[4] * dvy) + (a.M[8] * dvz + a.M[12] * dvw);
-      d.y = (a.M[1] * dvx + a.M[5] * dvy) + (a.M[9] * dvz + a.M[13] * dvw);
-      d.z = (a.M[2] * dvx + a.M[6] * dvy) + (a.M[10] * dvz + a.M[14] * dvw);
-      d.w = (a.M[3] * dvx + a.M[7] * dvy) + (a.M[11] * dvz + a.M[15] * dvw);
-      o = {a.cam_pos[0], a.cam_pos[1], a.cam_pos[2], a.cam_pos[3]};
+      d.x = (M[0] * dvx + M[4] * dvy) + (M[8] * dvz + M[12] * dvw);
+      d.y = (M[1] * dvx + M[5] * dvy) + (M[9] * dvz + M[13] * dvw);
+      d.z = (M[2] * dvx + M[6] * dvy) + (M[10] * dvz + M[14] * dvw);
+      d.w = (M[3] * dvx + M[7] * dvy) + (M[11] * dvz + M[15] * dvw);
+      o = {cam_pos[0], cam_pos[1], cam_pos[2], cam_pos[3]};
       ds = 0; shadow = false; fresh = false;
       if (STATS || LIST) st[ST_PATHS]++;
     }
@@ -759,10 +780,11 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           // transmittance, albedo) is evaluated when the path is completed, and only if the shadow
           // ray came through.
           V4 lp;
-          lp.x = a.light_pos[0] + (rng_next<RNG_MODE>(rng) * 2.0f - 1.0f) * 0.1f;
-          lp.y = a.light_pos[1];
-          lp.z = a.light_pos[2] + (rng_next<RNG_MODE>(rng) * 2.0f - 1.0f) * 0.1f;
-          lp.w = a.light_pos[3];
+          const float MIPT_CONST* light_pos = late_args()->light_pos;
+          lp.x = light_pos[0] + (rng_next<RNG_MODE>(rng) * 2.0f - 1.0f) * 0.1f;
+          lp.y = light_pos[1];
+          lp.z = light_pos[2] + (rng_next<RNG_MODE>(rng) * 2.0f - 1.0f) * 0.1f;
+          lp.w = light_pos[3];
           const V4 at = medium ? o : pos;
           const V4 v = sub4(lp, at);
           const V4 vecr = normalize4(v);
@@ -830,12 +852,13 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           } else if (mat == MIPT_MAT_GLASS) {
             // bounceGlass (pathtracer.cpp:29-63)
             if (STATS) st[ST_GLASS]++;
-            const float R0 = a.glass_R0;
-            float eta = a.eta_enter;
+            const PathArgs MIPT_CONST* kg = late_args();
+            const float R0 = kg->glass_R0, eta_enter = kg->eta_enter, eta_exit = kg->eta_exit;
+            float eta = eta_enter;
             V4 n = nrm;
             if (dot4(n, d) > 0.f) {  // inside the glass
               n = scale4(n, -1.0f);
-              eta = a.eta_exit;
+              eta = eta_exit;
             }
             const float c = dot4(n, d) * -1.0f;
             const float cost1 = (c < 0.f) ? 0.f : c;
@@ -923,14 +946,18 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
         const float den = (float)(((4.0 * 3.14159) * (double)r) * (double)r);  // light.cpp:22
         const float tr = fog ? fog_expf(-(P.fog_sigma_t * r)) : 1.0f;  // transmittance to the light
         float cr, cg, cb;
+        const PathArgs MIPT_CONST* kc = late_args();
+        const float light_col[3] = {kc->light_col[0], kc->light_col[1], kc->light_col[2]};
+        const uint32_t light_gray = kc->light_gray;
+        const float glass_weight = kc->p.glass_weight, diffuse_weight = kc->p.diffuse_weight, fog_albedo = kc->p.fog_albedo;
         if (tprim != TERMINAL_IN_MEDIUM) {
           const ShadeRec sh = shade_tab[tprim];
-          cr = (a.light_col[0] * m) / den;
-          if (a.light_gray) {
+          cr = (light_col[0] * m) / den;
+          if (light_gray) {
             cg = cr; cb = cr;
           } else {
-            cg = (a.light_col[1] * m) / den;
-            cb = (a.light_col[2] * m) / den;
+            cg = (light_col[1] * m) / den;
+            cb = (light_col[2] * m) / den;
           }
           if (fog) { cr = cr * tr; cg = cg * tr; cb = cb * tr; }
           if (sh.material != MIPT_MAT_GLASS) {  // pathtracer.cpp:88-93
@@ -938,17 +965,17 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           }
         } else {
           const float phase = 1.0f / (4.0f * 3.14159f);
-          cr = (((a.light_col[0] * phase) / den) * tr) * P.fog_albedo;
-          cg = (((a.light_col[1] * phase) / den) * tr) * P.fog_albedo;
-          cb = (((a.light_col[2] * phase) / den) * tr) * P.fog_albedo;
+          cr = (((light_col[0] * phase) / den) * tr) * fog_albedo;
+          cg = (((light_col[1] * phase) / den) * tr) * fog_albedo;
+          cb = (((light_col[2] * phase) / den) * tr) * fog_albedo;
         }
         // unwind the recursion, deepest vertex first
         for (int k = job_sp - 1; k >= 0; --k) {
           const uint32_t tag = tags[((size_t)(b * P.max_depth + k)) * BLOCK + tid];
           if (tag == TAGV_GLASS) {  // pathtracer.cpp:62
-            cr = (cr * 1.0f) * P.glass_weight; cg = (cg * 1.0f) * P.glass_weight; cb = (cb * 1.0f) * P.glass_weight;
+            cr = (cr * 1.0f) * glass_weight; cg = (cg * 1.0f) * glass_weight; cb = (cb * 1.0f) * glass_weight;
           } else if (tag == TAGV_FOG) {
-            cr = cr * P.fog_albedo; cg = cg * P.fog_albedo; cb = cb * P.fog_albedo;
+            cr = cr * fog_albedo; cg = cg * fog_albedo; cb = cb * fog_albedo;
           } else {  // pathtracer.cpp:18, with the direction of the last segment
             const ShadeRec sv = shade_tab[tag];
             V4 N = {sv.nx, sv.ny, sv.nz, sv.nw};
@@ -957,9 +984,9 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
               N = {q[0], q[1], q[2], q[3]};
             }
             const float dn = dot4(dfin, N);
-            cr = (((cr * sv.r) * dn) * 1.0f) * P.diffuse_weight;
-            cg = (((cg * sv.g) * dn) * 1.0f) * P.diffuse_weight;
-            cb = (((cb * sv.b) * dn) * 1.0f) * P.diffuse_weight;
+            cr = (((cr * sv.r) * dn) * 1.0f) * diffuse_weight;
+            cg = (((cg * sv.g) * dn) * 1.0f) * diffuse_weight;
+            cb = (((cb * sv.b) * dn) * 1.0f) * diffuse_weight;
           }
         }
         const float sr = park[c0 + 0][tid] + cr, sg = park[c0 + 1][tid] + cg, sb = park[c0 + 2][tid] + cb;  // main.cpp:137
