@@ -665,9 +665,15 @@ __device__ __forceinline__ void tri_test(TP T, int i, float ox, float oy, float 
   if (FAST) {
     r0 = __builtin_amdgcn_rcpf(detA);
     const float qa = detM * r0;
-    const bool pos = qa >= 1e-30f && qa <= 1e30f;  // finite and clearly positive
+    // 1e-30 <= qa <= 1e30 (finite and clearly positive) and -1e30 <= qa <= -1e-30, each as ONE
+    // unsigned comparison of the bit pattern (floats of one sign order like their bits; a NaN, a
+    // zero, a subnormal or a value of the other sign lands outside): half the vector and scalar
+    // instructions of four float comparisons with their constants and the ANDs between them
+    const uint32_t qi = __float_as_uint(qa);
+    const bool pos = qi - 0x0DA24260u <= 0x63A7B06Au;
+    const bool neg = qi - 0x8DA24260u <= 0x63A7B06Au;
     const bool sure_pass = pos && qa <= h.lim_lo;
-    const bool sure_fail = (qa <= -1e-30f && qa >= -1e30f) || (pos && qa >= h.lim_hi);
+    const bool sure_fail = neg || (pos && qa >= h.lim_hi);
     pass = sure_pass;
     if (!sure_pass && !sure_fail) {
       const float t = detM / detA;  // :23
