@@ -852,8 +852,13 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           } else if (mat == MIPT_MAT_GLASS) {
             // bounceGlass (pathtracer.cpp:29-63)
             if (STATS) st[ST_GLASS]++;
+            // (read here like the camera and the light; the empty asm statement pins the two indices in
+            // scalar registers -- without it the compiler selects between their ADDRESSES per lane and
+            // fetches the chosen one with a vector load the branch then waits for)
             const PathArgs MIPT_CONST* kg = late_args();
-            const float R0 = kg->glass_R0, eta_enter = kg->eta_enter, eta_exit = kg->eta_exit;
+            const float R0 = kg->glass_R0;
+            float eta_enter = kg->eta_enter, eta_exit = kg->eta_exit;
+            asm volatile("" : "+s"(eta_enter), "+s"(eta_exit));
             float eta = eta_enter;
             V4 n = nrm;
             if (dot4(n, d) > 0.f) {  // inside the glass
