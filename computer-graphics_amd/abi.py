@@ -86,7 +86,7 @@ EXPORTS = [
     "mipt_scene_destroy", "mipt_closest_hit", "mipt_any_hit", "mipt_render_accumulate",
     "mipt_resolve_argb", "mipt_trace_paths", "mipt_closest_hit_dev", "mipt_any_hit_dev",
     "mipt_render_accumulate_dev", "mipt_resolve_argb_dev", "mipt_get_stats", "mipt_path_key",
-    "mipt_load_test_model", "mipt_default_camera", "mipt_default_light", "mipt_debug_selfcheck", "mipt_scene_has_bvh", "mipt_scene_pair_units", "mipt_scene_axis_pair_units", "mipt_scene_box_units", "mipt_load_obj", "mipt_normalise_triangles", "mipt_save_bmp", "mipt_frame_create", "mipt_frame_destroy", "mipt_frame_reset",
+    "mipt_load_test_model", "mipt_default_camera", "mipt_default_light", "mipt_debug_selfcheck", "mipt_scene_has_bvh", "mipt_scene_pair_units", "mipt_scene_axis_pair_units", "mipt_scene_box_units", "mipt_plan_scan_units", "mipt_load_obj", "mipt_normalise_triangles", "mipt_save_bmp", "mipt_frame_create", "mipt_frame_destroy", "mipt_frame_reset",
     "mipt_frame_add_samples", "mipt_frame_present", "mipt_frame_read_pixels", "mipt_frame_samples",
     "mipt_render_accumulate_noalloc_dev", "mipt_scene_create_opts",
     "mipt_multi_create", "mipt_multi_destroy", "mipt_multi_device_count", "mipt_multi_render_accumulate",
@@ -169,6 +169,7 @@ def load_library(path=None):
     lib.mipt_scene_pair_units.argtypes = [vp]
     lib.mipt_scene_axis_pair_units.argtypes = [vp]
     lib.mipt_scene_box_units.argtypes = [vp]
+    lib.mipt_plan_scan_units.argtypes = [vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.mipt_save_bmp.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
     lib.mipt_frame_create.argtypes = [vp, C.c_int, C.c_int, P(vp)]
     lib.mipt_frame_destroy.argtypes = [vp]

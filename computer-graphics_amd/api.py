@@ -46,6 +46,16 @@ def load_test_model(which):
     return tris[:n].copy()
 
 
+def plan_scan_units(tris):
+    """(coplanar pairs, pairs in axis planes, boxes) the linear scan's candidate filter would form over
+    these triangles; computed on the host, no GPU needed."""
+    lib = abi.load_library()
+    tris = np.ascontiguousarray(tris)
+    pairs, axis, boxes = C.c_int(), C.c_int(), C.c_int()
+    _check(lib.mipt_plan_scan_units(_ptr(tris), len(tris), C.byref(pairs), C.byref(axis), C.byref(boxes)))
+    return pairs.value, axis.value, boxes.value
+
+
 def load_obj(path):
     """LoadObject (parser.cpp:8-46): the triangles of an OBJ file as a TRIANGLE_DTYPE array."""
     lib = abi.load_library()

@@ -721,15 +721,11 @@ static int upload_scan_units(MiptScene* s, const std::vector<ScanUnit>& units) {
   return MIPT_OK;
 }
 
-static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
-                             size_t n_spheres, int device, uint32_t options, MiptScene* s) {
-  s->device = device;
-  HIP_TRY(hipSetDevice(device));
-  std::vector<TriRec> tr(n_tris + 2);  // two records of padding: the scan prefetches ahead
+// The per-triangle records of the scan (TriRec in mipt_device.hpp) and the largest |coordinate|.
+static void make_tri_recs(const MiptTriangle* tris, size_t n_tris, std::vector<TriRec>& tr, float& scale) {
+  tr.assign(n_tris + 2, TriRec{});  // two records of padding: the scan prefetches ahead
   memset(tr.data(), 0, tr.size() * sizeof(TriRec));
-  std::vector<ShadeRec> sh(n_tris + n_spheres ? n_tris + n_spheres : 1);
-  std::vector<SphereRec> sp(n_spheres ? n_spheres : 1);
-  float scale = 0.f;
+  scale = 0.f;
   for (size_t i = 0; i < n_tris; ++i) {
     const MiptTriangle& t = tris[i];
     TriRec& r = tr[i];
@@ -759,6 +755,20 @@ static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const Mipt
     r.kA = sane ? (0.000244140625f * FILTER_TIGHT) * (E1 * E2) : INFINITY;  // 2^-12
     r.kB = sane ? 7.62939453125e-06f * std::fmax(E1, E2) : 0.f;  // 2^-17
     r.kT = sane ? 7.62939453125e-06f * (E1 * E2) : 0.f;
+  }
+}
+
+static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
+                             size_t n_spheres, int device, uint32_t options, MiptScene* s) {
+  s->device = device;
+  HIP_TRY(hipSetDevice(device));
+  std::vector<TriRec> tr;
+  float scale = 0.f;
+  make_tri_recs(tris, n_tris, tr, scale);
+  std::vector<ShadeRec> sh(n_tris + n_spheres ? n_tris + n_spheres : 1);
+  std::vector<SphereRec> sp(n_spheres ? n_spheres : 1);
+  for (size_t i = 0; i < n_tris; ++i) {
+    const MiptTriangle& t = tris[i];
     ShadeRec& q = sh[i];
     q.nx = t.normal[0]; q.ny = t.normal[1]; q.nz = t.normal[2]; q.nw = t.normal[3];
     q.r = t.color[0]; q.g = t.color[1]; q.b = t.color[2];
@@ -879,6 +889,30 @@ static inline unsigned batch_grid(size_t n_rays) {
 extern "C" int mipt_scene_pair_units(MiptScene* s) { return s ? (int)s->n_pair_units : 0; }
 extern "C" int mipt_scene_axis_pair_units(MiptScene* s) { return s ? (int)s->n_axis_units : 0; }
 extern "C" int mipt_scene_box_units(MiptScene* s) { return s ? (int)s->n_box_units : 0; }
+
+extern "C" int mipt_plan_scan_units(const MiptTriangle* tris, size_t n_tris, int* pair_units, int* axis_pair_units,
+                                    int* box_units) {
+  if (n_tris && !tris) return fail(MIPT_E_INVALID, "mipt_plan_scan_units: null triangle array");
+  if (n_tris > (size_t)1 << 24) return fail(MIPT_E_INVALID, "mipt_plan_scan_units: too many triangles (%zu)", n_tris);
+  try {
+    std::vector<TriRec> tr;
+    float scale = 0.f;
+    make_tri_recs(tris, n_tris, tr, scale);
+    std::vector<int> all(n_tris);
+    for (size_t i = 0; i < n_tris; ++i) all[i] = (int)i;
+    std::vector<ScanUnit> units;
+    uint32_t np = 0, na = 0, nb = 0;
+    build_scan_units(tris, tr, all, units, np, na, nb);
+    if (pair_units) *pair_units = (int)np;
+    if (axis_pair_units) *axis_pair_units = (int)na;
+    if (box_units) *box_units = (int)nb;
+  } catch (const std::bad_alloc&) {
+    return fail(MIPT_E_NOMEM, "mipt_plan_scan_units: host allocation failed");
+  } catch (...) {
+    return fail(MIPT_E_INVALID, "mipt_plan_scan_units: unexpected exception");
+  }
+  return MIPT_OK;
+}
 
 // Tree batches of SORT_MIN_RAYS rays or more: bin the rays by origin cell unless they come coherent.
 // On return b.order is null (walk the rays as they come) or b holds the batch in walking order and

@@ -222,6 +222,11 @@ int mipt_scene_axis_pair_units(MiptScene* scene);
  * into the parallelepiped's frame once and tests all its faces there. The pairs inside such a
  * group still count in mipt_scene_pair_units. No counterpart in the reference. */
 int mipt_scene_box_units(MiptScene* scene);
+/* The same three counts for a list of triangles scanned linearly, computed on the host alone (no
+ * GPU, no scene): how the filter would group them. Outputs are nullable. No counterpart in the
+ * reference. */
+int mipt_plan_scan_units(const MiptTriangle* tris, size_t n_tris, int* pair_units, int* axis_pair_units,
+                         int* box_units);
 void mipt_scene_destroy(MiptScene* scene);
 
 /* Batch closestIntersection (intersections.cpp:6-55). Host pointers.

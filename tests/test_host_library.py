@@ -98,6 +98,59 @@ def test_argument_checks_need_no_gpu(pkg, lib):
     lib.mipt_frame_destroy(None)
 
 
+def _box(r, F, faces=((0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1))):
+    """Triangles of the listed faces (axis, side) of the parallelepiped r + F [0,1]^3, two per face."""
+    v = []
+    for w, side in faces:
+        ip, iq = (w + 1) % 3, (w + 2) % 3
+
+        def at(p, q):
+            c = np.zeros(3)
+            c[w], c[ip], c[iq] = side, p, q
+            return np.float32(r + F @ c)
+        P = [at(0, 0), at(1, 0), at(1, 1), at(0, 1)]
+        v += [(P[0], P[1], P[2]), (P[0], P[2], P[3])]
+    return v
+
+
+def test_scan_unit_planner_groups_walls_and_blocks(pkg, lib):
+    # host logic of the linear scan's candidate filter, no GPU: which triangles become coplanar pairs,
+    # which pairs lie in axis planes, which pairs are faces of one parallelepiped (box units)
+    api, abi = pkg.api, pkg.abi
+    # LoadTestModelGlassCube (TestModelH.h:351-482): 5 walls, 5 faces of the block, the mirror = 11 pairs; the
+    # walls and the block's top in axis planes; the walls one box, the block's sides two two-face boxes
+    assert api.plan_scan_units(api.load_test_model(abi.SCENE_GLASS_CUBE)) == (11, 6, 3)
+    # LoadTestModel (TestModelH.h:55-201): 5 walls + 2 x (4 sides + top) = 15 pairs, 7 in axis planes, 5 boxes
+    assert api.plan_scan_units(api.load_test_model(abi.SCENE_CORNELL)) == (15, 7, 5)
+    assert api.plan_scan_units(np.zeros(0, dtype=abi.TRIANGLE_DTYPE)) == (0, 0, 0)
+
+    def scene(tri_list):
+        t = np.zeros(len(tri_list), dtype=abi.TRIANGLE_DTYPE)
+        for k, (a, b, c) in enumerate(tri_list):
+            t["v0"][k, :3], t["v1"][k, :3], t["v2"][k, :3] = a, b, c
+            t["v0"][k, 3] = t["v1"][k, 3] = t["v2"][k, 3] = 1.0
+        return t
+    rng = np.random.default_rng(7)
+    Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    F = Q * np.array([0.5, 0.3, 0.7])
+    r = np.array([0.1, -0.2, 0.05])
+    # a turned box with all six faces: 6 pairs, none in an axis plane, one box
+    assert api.plan_scan_units(scene(_box(r, F))) == (6, 0, 1)
+    # two turned faces that meet in an edge make a box, two axis-plane faces do not (their own form is as cheap)
+    assert api.plan_scan_units(scene(_box(r, F, ((0, 0), (1, 0))))) == (2, 0, 1)
+    assert api.plan_scan_units(scene(_box(r, np.diag([0.5, 0.3, 0.7]), ((0, 0), (1, 0))))) == (2, 2, 0)
+    # two parallel faces share no edge: pairs, no box
+    assert api.plan_scan_units(scene(_box(r, F, ((0, 0), (0, 1))))) == (2, 0, 0)
+    # one corner moved by 10^-3 of the size: the faces at that corner are no parallelograms any more, the
+    # three others still make a box
+    moved = _box(r, F)
+    far = np.float32(r + F @ np.ones(3))
+    moved = [tuple(np.float32(p + F[:, 0] * 1e-3) if np.array_equal(p, far) else p for p in tri) for tri in moved]
+    pairs, axis, boxes = api.plan_scan_units(scene(moved))
+    assert boxes == 1 and axis == 0 and pairs <= 6
+    assert lib.mipt_plan_scan_units(None, 3, None, None, None) == abi.MIPT_E_INVALID
+
+
 def test_missing_library_fails_loudly(pkg, tmp_path):
     with pytest.raises(pkg.abi.MiptLibraryMissing):
         pkg.abi.load_library(str(tmp_path / "libmipt.so"))
