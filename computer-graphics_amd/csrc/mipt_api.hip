@@ -92,6 +92,10 @@ struct MiptScene {
   uint32_t* d_queue = nullptr;
   float* d_partial = nullptr;
   size_t partial_bytes = 0;
+  // staging memory of the entry points that take HOST pointers (device copies of their arguments):
+  // kept and grown on demand, so that a loop over such calls does not allocate and free every time
+  void* d_stage = nullptr;
+  size_t stage_bytes = 0;
   BvhNode* d_bvh = nullptr;
   // ray binning of the large tree batches: (cell key, ray index) pairs, sorted copy, rocPRIM's
   // temporary storage, and the coherence probe's counter; grown on demand, kept with the scene
@@ -134,6 +138,7 @@ static void scene_free(MiptScene* s) {
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_queue) (void)hipFree(s->d_queue);
   if (s->d_partial) (void)hipFree(s->d_partial);
+  if (s->d_stage) (void)hipFree(s->d_stage);
   if (s->d_bvh) (void)hipFree(s->d_bvh);
   if (s->d_big) (void)hipFree(s->d_big);
   if (s->d_sort) (void)hipFree(s->d_sort);
@@ -173,6 +178,30 @@ struct DevBuf {
 };
 
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+// The scene's staging memory, at least `bytes` large (the host-pointer entry points synchronise before
+// they return, so the memory is free again whenever one of them starts), handed out in 256-byte steps.
+static inline size_t stage_round(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+static int stage_reserve(MiptScene* s, size_t bytes) {
+  if (bytes <= s->stage_bytes) return MIPT_OK;
+  if (s->d_stage) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(s->d_stage));
+    s->d_stage = nullptr;
+    s->stage_bytes = 0;
+  }
+  HIP_TRY(hipMalloc(&s->d_stage, bytes));
+  s->stage_bytes = bytes;
+  return MIPT_OK;
+}
+struct StageCursor {
+  char* at;
+  template <typename T> T* take(size_t bytes) {
+    T* p = reinterpret_cast<T*>(at);
+    at += stage_round(bytes);
+    return p;
+  }
+};
 
 // LBVH over the triangles listed in `subset` (n >= 2 of them): bounds -> Morton keys -> radix sort
 // -> binary topology -> refit waves -> collapse into four-wide nodes, level by level. Everything runs on the null stream of the scene's device; the tree
@@ -1049,22 +1078,25 @@ extern "C" int mipt_closest_hit(MiptScene* s, const float* origin4, const float*
   if (n_rays == 0) return MIPT_OK;
   if (!origin4 || !dir4 || !tri_idx || !t) return fail(MIPT_E_INVALID, "mipt_closest_hit: null buffer");
   HIP_TRY(hipSetDevice(s->device));
-  DevBuf o, d, idx, tt, pos;
-  HIP_TRY(o.alloc(n_rays * 16)); HIP_TRY(d.alloc(n_rays * 16));
-  HIP_TRY(idx.alloc(n_rays * 4)); HIP_TRY(tt.alloc(n_rays * 4));
-  if (position4) HIP_TRY(pos.alloc(n_rays * 16));
-  HIP_TRY(hipMemcpy(o.p, origin4, n_rays * 16, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d.p, dir4, n_rays * 16, hipMemcpyHostToDevice));
+  int rc = stage_reserve(s, 3 * stage_round(n_rays * 16) + 2 * stage_round(n_rays * 4));
+  if (rc != MIPT_OK) return rc;
+  StageCursor st{static_cast<char*>(s->d_stage)};
+  float* o = st.take<float>(n_rays * 16);
+  float* d = st.take<float>(n_rays * 16);
+  float* pos = st.take<float>(n_rays * 16);
+  int32_t* idx = st.take<int32_t>(n_rays * 4);
+  float* tt = st.take<float>(n_rays * 4);
+  HIP_TRY(hipMemcpy(o, origin4, n_rays * 16, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d, dir4, n_rays * 16, hipMemcpyHostToDevice));
   // outputs keep the caller's values where the kernel does not write (t / position on a miss)
-  HIP_TRY(hipMemcpy(tt.p, t, n_rays * 4, hipMemcpyHostToDevice));
-  if (position4) HIP_TRY(hipMemcpy(pos.p, position4, n_rays * 16, hipMemcpyHostToDevice));
-  int rc = mipt_closest_hit_dev(s, o.as<float>(), d.as<float>(), n_rays, idx.as<int32_t>(), tt.as<float>(),
-                                position4 ? pos.as<float>() : nullptr, nullptr);
+  HIP_TRY(hipMemcpy(tt, t, n_rays * 4, hipMemcpyHostToDevice));
+  if (position4) HIP_TRY(hipMemcpy(pos, position4, n_rays * 16, hipMemcpyHostToDevice));
+  rc = mipt_closest_hit_dev(s, o, d, n_rays, idx, tt, position4 ? pos : nullptr, nullptr);
   if (rc != MIPT_OK) return rc;
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(tri_idx, idx.p, n_rays * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(t, tt.p, n_rays * 4, hipMemcpyDeviceToHost));
-  if (position4) HIP_TRY(hipMemcpy(position4, pos.p, n_rays * 16, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(tri_idx, idx, n_rays * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(t, tt, n_rays * 4, hipMemcpyDeviceToHost));
+  if (position4) HIP_TRY(hipMemcpy(position4, pos, n_rays * 16, hipMemcpyDeviceToHost));
   return MIPT_OK;
 }
 
@@ -1074,16 +1106,20 @@ extern "C" int mipt_any_hit(MiptScene* s, const float* origin4, const float* dir
   if (n_rays == 0) return MIPT_OK;
   if (!origin4 || !dir4 || !max_t || !occluded) return fail(MIPT_E_INVALID, "mipt_any_hit: null buffer");
   HIP_TRY(hipSetDevice(s->device));
-  DevBuf o, d, m, occ;
-  HIP_TRY(o.alloc(n_rays * 16)); HIP_TRY(d.alloc(n_rays * 16));
-  HIP_TRY(m.alloc(n_rays * 4)); HIP_TRY(occ.alloc(n_rays));
-  HIP_TRY(hipMemcpy(o.p, origin4, n_rays * 16, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d.p, dir4, n_rays * 16, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(m.p, max_t, n_rays * 4, hipMemcpyHostToDevice));
-  int rc = mipt_any_hit_dev(s, o.as<float>(), d.as<float>(), m.as<float>(), n_rays, occ.as<uint8_t>(), nullptr);
+  int rc = stage_reserve(s, 2 * stage_round(n_rays * 16) + stage_round(n_rays * 4) + stage_round(n_rays));
+  if (rc != MIPT_OK) return rc;
+  StageCursor st{static_cast<char*>(s->d_stage)};
+  float* o = st.take<float>(n_rays * 16);
+  float* d = st.take<float>(n_rays * 16);
+  float* m = st.take<float>(n_rays * 4);
+  uint8_t* occ = st.take<uint8_t>(n_rays);
+  HIP_TRY(hipMemcpy(o, origin4, n_rays * 16, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d, dir4, n_rays * 16, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m, max_t, n_rays * 4, hipMemcpyHostToDevice));
+  rc = mipt_any_hit_dev(s, o, d, m, n_rays, occ, nullptr);
   if (rc != MIPT_OK) return rc;
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(occluded, occ.p, n_rays, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(occluded, occ, n_rays, hipMemcpyDeviceToHost));
   return MIPT_OK;
 }
 
@@ -1362,13 +1398,14 @@ extern "C" int mipt_render_accumulate(MiptScene* s, const MiptCamera* cam, const
   if (!accum_rgb) return fail(MIPT_E_INVALID, "mipt_render_accumulate: accumulation buffer is null");
   HIP_TRY(hipSetDevice(s->device));
   const size_t bytes = (size_t)p->width * p->height * 3 * sizeof(float);
-  DevBuf acc;
-  HIP_TRY(acc.alloc(bytes));
-  HIP_TRY(hipMemcpy(acc.p, accum_rgb, bytes, hipMemcpyHostToDevice));
-  rc = mipt_render_accumulate_dev(s, cam, light, p, sample_begin, sample_count, acc.as<float>(), nullptr);
+  rc = stage_reserve(s, bytes);
+  if (rc != MIPT_OK) return rc;
+  float* acc = static_cast<float*>(s->d_stage);
+  HIP_TRY(hipMemcpy(acc, accum_rgb, bytes, hipMemcpyHostToDevice));
+  rc = mipt_render_accumulate_dev(s, cam, light, p, sample_begin, sample_count, acc, nullptr);
   if (rc != MIPT_OK) return rc;
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(accum_rgb, acc.p, bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(accum_rgb, acc, bytes, hipMemcpyDeviceToHost));
   return MIPT_OK;
 }
 

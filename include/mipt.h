@@ -17,6 +17,9 @@
  * and tree-batch launch uses: launches of one scene are ordered on the device in
  * call order, whichever streams they were given (each waits for an event its
  * predecessor recorded), so frames or streams sharing a scene never overlap there.
+ * The entry points that take HOST pointers stage their arguments in device memory the
+ * scene keeps and grows on demand (no allocation per call once it is large enough) and
+ * return after the device has finished; the *_dev variants neither copy nor wait.
  *
  * Arithmetic contract: IEEE-754 binary32, every product and sum separately
  * rounded (no FMA contraction), correctly rounded division and square root,
