@@ -123,7 +123,7 @@ struct __attribute__((aligned(64))) BoxUnit {
   float c0;       // constant part of delta
   float k6;       // 2 * 6 eps kappa, with a safety factor
   uint32_t meta;  // chunk counts when this is the chunk's first record (see unit_mask)
-  struct Axis {      // what one axis needs, side by side (one scalar load)
+  struct Axis {      // what one axis needs (the record's second 64 bytes: dwords 5 w .. 5 w + 4)
     float kA;        // `well` threshold
     float kh;        // first-order coefficient of delta
     float kT;        // coefficient of dt
@@ -592,10 +592,26 @@ __device__ __forceinline__ uint32_t unit_mask(const ScanUnit* chunk, V4 o, V4 d,
   uint32_t mask = 0;
   {
     const BoxUnit MIPT_CONST* boxes = reinterpret_cast<const BoxUnit MIPT_CONST*>(units);
-    // (rolled, fields read where they are used: copying the record into registers up front costs
-    // a dozen more spilled scalar registers than the waits it saves)
+    // (rolled; the whole record in two 64-byte scalar loads issued together: read field by field,
+    // the compiler sinks the loads into the per-axis code and waits out each of them there)
 #pragma unroll 1
-    for (int k = 0; k < n_box; ++k) box_candidates(boxes + k, o, d, Dm, mask);
+    for (int k = 0; k < n_box; ++k) {
+      typedef uint32_t Dwords16 __attribute__((ext_vector_type(16)));
+      const Dwords16 MIPT_CONST* P = reinterpret_cast<const Dwords16 MIPT_CONST*>(boxes + k);
+      const Dwords16 lo16 = P[0], hi16 = P[1];
+      BoxUnit R;
+      R.rx = __uint_as_float(lo16[0]); R.ry = __uint_as_float(lo16[1]); R.rz = __uint_as_float(lo16[2]);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R.m[i] = __uint_as_float(lo16[3 + i]);
+      R.rmax = __uint_as_float(lo16[12]); R.c0 = __uint_as_float(lo16[13]); R.k6 = __uint_as_float(lo16[14]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        R.ax[i].kA = __uint_as_float(hi16[5 * i]); R.ax[i].kh = __uint_as_float(hi16[5 * i + 1]);
+        R.ax[i].kT = __uint_as_float(hi16[5 * i + 2]); R.ax[i].rw = __uint_as_float(hi16[5 * i + 3]);
+        R.ax[i].faces = hi16[5 * i + 4];
+      }
+      box_candidates(&R, o, d, Dm, mask);
+    }
     units += 2 * n_box;
   }
   // axis-plane pairs come sorted by axis; the ray is permuted once per run of equal axes.
