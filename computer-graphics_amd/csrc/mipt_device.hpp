@@ -31,11 +31,13 @@ constexpr int BLOCK = 256;  // threads per workgroup of every kernel
 //                                            (tri_candidate): 2^-12 |e1|oo |e2|oo,
 //                                            2^-17 max(|e1|oo, |e2|oo), 2^-17 |e1|oo |e2|oo;
 //                                            kA = +inf marks a triangle the filter never rejects
+// Order: the twelve values a lane's own test of ITS candidate fetches (v0, e1, e2, c0..c2) fill the
+// first 48 bytes -- three 16-byte LDS reads.
 struct __attribute__((aligned(64))) TriRec {
-  float v0x, v0y, v0z, v0w;
-  float e1x, e1y, e1z, c0;
-  float e2x, e2y, e2z, c1;
-  float c2, kA, kB, kT;
+  float v0x, v0y, v0z, c0;
+  float e1x, e1y, e1z, c1;
+  float e2x, e2y, e2z, c2;
+  float v0w, kA, kB, kT;
 };
 
 // ShadeRec: what shading needs about the ONE primitive a ray hit; gathered per lane. For
