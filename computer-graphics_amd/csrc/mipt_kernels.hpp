@@ -975,24 +975,27 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           cb = (((light_col[2] * phase) / den) * tr) * fog_albedo;
         }
         // unwind the recursion, deepest vertex first
+        // (one straight body for the three kinds of vertex, selected by the tag: as three nested
+        // per-lane branches a level cost ~30 scalar instructions for the execution masks, and the jobs of
+        // a flush are of mixed kinds at every level anyway. x * 1.0f is x.)
         for (int k = job_sp - 1; k >= 0; --k) {
           const uint32_t tag = tags[((size_t)(b * P.max_depth + k)) * BLOCK + tid];
-          if (tag == TAGV_GLASS) {  // pathtracer.cpp:62
-            cr = (cr * 1.0f) * glass_weight; cg = (cg * 1.0f) * glass_weight; cb = (cb * 1.0f) * glass_weight;
-          } else if (tag == TAGV_FOG) {
-            cr = cr * fog_albedo; cg = cg * fog_albedo; cb = cb * fog_albedo;
-          } else {  // pathtracer.cpp:18, with the direction of the last segment
-            const ShadeRec sv = shade_tab[tag];
-            V4 N = {sv.nx, sv.ny, sv.nz, sv.nw};
-            if ((int)tag >= a.sc.n_tris) {
-              const float* q = sph_n + ((size_t)k * BLOCK + tid) * 4;
-              N = {q[0], q[1], q[2], q[3]};
-            }
-            const float dn = dot4(dfin, N);
-            cr = (((cr * sv.r) * dn) * 1.0f) * diffuse_weight;
-            cg = (((cg * sv.g) * dn) * 1.0f) * diffuse_weight;
-            cb = (((cb * sv.b) * dn) * 1.0f) * diffuse_weight;
+          const bool is_glass = tag == TAGV_GLASS, is_fog = tag == TAGV_FOG;
+          const bool is_dif = !(is_glass | is_fog);
+          const uint32_t prim = is_dif ? tag : 0u;  // the others read record 0 and do not use it
+          const ShadeRec sv = shade_tab[prim];
+          V4 N = {sv.nx, sv.ny, sv.nz, sv.nw};
+          if (a.sc.n_spheres > 0 && (int)prim >= a.sc.n_tris) {
+            const float* q = sph_n + ((size_t)k * BLOCK + tid) * 4;
+            N = {q[0], q[1], q[2], q[3]};
           }
+          const float dn = dot4(dfin, N);
+          // glass: (c * 1) * weight (pathtracer.cpp:62); fog: c * albedo; diffuse, with the direction of
+          // the last segment: (((c * colour) * dn) * 1) * weight (pathtracer.cpp:18)
+          const float w = is_glass ? glass_weight : (is_fog ? fog_albedo : diffuse_weight);
+          float tr_ = is_dif ? cr * sv.r : cr, tg_ = is_dif ? cg * sv.g : cg, tb_ = is_dif ? cb * sv.b : cb;
+          tr_ = is_dif ? tr_ * dn : tr_; tg_ = is_dif ? tg_ * dn : tg_; tb_ = is_dif ? tb_ * dn : tb_;
+          cr = tr_ * w; cg = tg_ * w; cb = tb_ * w;
         }
         const float sr = park[c0 + 0][tid] + cr, sg = park[c0 + 1][tid] + cg, sb = park[c0 + 2][tid] + cb;  // main.cpp:137
         park[c0 + 0][tid] = sr; park[c0 + 1][tid] = sg; park[c0 + 2][tid] = sb;
