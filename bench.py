@@ -38,6 +38,7 @@ SPP_CONFIG1 = 1024   # BASELINE configs[1]
 SPP_CONFIG2 = 4096   # BASELINE configs[2], split over the ranks
 FOG_SIGMA_T = 0.1    # builder's choice for the "+ fog" of configs[1]; the reference has no fog code
 FOG_ALBEDO = 0.8
+C5_ALGORITHMIC_BYTES_PER_RAY = 3963   # 55.7 nodes + 5.6 triangle records of 64 B + 40 B per ray (stats kernel, configs[4])
 # algorithmic work of the reference's triangle test: 26 flop for the determinant-ratio gate,
 # 79 more when the gate passes (inverse, mat*vec, barycentric sum, position)
 FLOP_GATE, FLOP_INVERSE = 26, 79
@@ -153,39 +154,54 @@ def cpu_baseline(abi, tris, light, params):
 
 
 def load_counters(name):
-    """Per-launch hardware counters of a kernel from the committed rocprofv3 --pmc passes."""
+    """Per-launch hardware counters of a kernel from the committed rocprofv3 --pmc passes
+    (tools/profile_round.sh -> tools/counters_json.py). The file names the hash of the sources it was
+    measured on; counters of other code are not reported: returns (counters or None, stale)."""
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
-            return json.load(f)
+            hw = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, False
+    if hw.get("source_hash") != graft.kernel_source_hash():
+        return None, True
+    return hw, False
 
 
-def init_ranks(rehearse=False):
+_COLLECTIVES = None   # backend of the process group, if one was made
+
+
+def init_ranks(rehearse=False, force_dist=False):
     """rehearse: every rank on GPU 0 and gloo for the collectives (RCCL refuses two ranks on one device):
-    the N-rank code path on a one-GPU machine, for checking it -- the timings mean nothing."""
+    the N-rank code path on a one-GPU machine, for checking it -- the timings mean nothing.
+    force_dist: make the process group even for a world of one rank, so that the RCCL backend's
+    initialisation, barrier, reduce and all-reduce run on a one-GPU machine exactly as with N ranks."""
+    global _COLLECTIVES
     import torch
     import torch.distributed as dist
     world, rank, local_rank = rank_env()
     if rehearse:
         local_rank = 0
-    if world > 1:
+    grouped = world > 1 or force_dist
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port())
         torch.cuda.set_device(local_rank)
         if rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        _COLLECTIVES = "gloo" if rehearse else "nccl"
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(dt):
-        if world > 1:
+        if grouped:
             t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
@@ -195,7 +211,7 @@ def init_ranks(rehearse=False):
 
 
 def finish_ranks(world):
-    if world > 1:
+    if _COLLECTIVES:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
@@ -209,7 +225,7 @@ def tree_workload(args):
     import bigscenes
     import raygen
 
-    world, rank, dev, barrier, max_over_ranks = init_ranks(args.rehearse)
+    world, rank, dev, barrier, max_over_ranks = init_ranks(args.rehearse, args.force_dist)
     pkg = graft.load_package()
     abi, api = pkg.abi, pkg.api
     from computer_graphics_amd import parallel
@@ -235,7 +251,7 @@ def tree_workload(args):
                                         via_host=args.rehearse)
             else:
                 parallel.render_distributed(render, k * global_spp, global_spp, rank, world, buf, total,
-                                            via_host=args.rehearse)
+                                            via_host=args.rehearse, always=args.force_dist)
         units_per_step, unit = SIZE * SIZE * global_spp, "paths/s"
         label = (f"empty Cornell room + 102 400-triangle glass mesh (LBVH), {SIZE}x{SIZE}, {global_spp} spp per step"
                  f"{' split over the GPUs' if world > 1 else ''}, fog on; stand-in for BASELINE configs[3]")
@@ -265,7 +281,7 @@ def tree_workload(args):
                 "data": "synthetic", "config": {"workload": label, "parallelism": f"x{world}"}}
         if args.rehearse:
             line["rehearsal"] = "all ranks on one GPU, gloo through the host: not a measurement"
-        hw = load_counters(f"counters_bvh_{args.workload}.json")
+        hw, stale = load_counters(f"counters_bvh_{args.workload}.json")
         if args.workload == "c4":
             sp = abi.MiptParams.from_buffer_copy(bytes(params))
             sp.flags = abi.FLAG_STATS
@@ -278,19 +294,28 @@ def tree_workload(args):
             line["nodes_per_ray"] = st.bvh_nodes / rays
             line["leaves_per_ray"] = st.tri_tests / rays
         else:
-            bytes_per_unit = hw["algorithmic_bytes_per_ray"] if hw else None
-        if bytes_per_unit is not None:
-            ach = value / world * bytes_per_unit / 1e9
-            line["roofline"] = {
-                "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                "traffic": (hw or {}).get("hbm_bytes_per_launch"),
-                "l2_hit_rate": (hw or {}).get("l2_hit_rate"), "active_lanes": (hw or {}).get("active_lanes"),
-                "valu_issue_frac": (hw or {}).get("valu_issue_frac"),
-                "note": "achieved = ALGORITHMIC bytes per second per GPU: 64 per four-wide tree node fetched + 64 per "
-                        "triangle record looked at + 40 per ray. The gathers are dependent (a node's address "
-                        "comes out of the previous node), so the walk is bound by L2 / HBM LATENCY at the "
-                        "occupancy the registers allow, not by HBM bandwidth; traffic = HBM bytes per launch "
-                        "from the committed rocprofv3 --pmc passes (profiles/counters_bvh_*.json) when present"}
+            bytes_per_unit = C5_ALGORITHMIC_BYTES_PER_RAY
+        hw = hw or {}
+        # what the memory system actually moved: HBM bytes per launch from the counter passes over the
+        # launch's duration in those passes (null when the counters are of other code)
+        traffic = hw.get("hbm_bytes_per_launch")
+        measured = traffic / (hw["kernel_us"] * 1e-6) / 1e9 if traffic and hw.get("kernel_us") else None
+        lanes, issue = hw.get("active_lanes"), hw.get("valu_issue_frac")
+        line["roofline"] = {
+            "bound": "latency", "achieved": measured, "peak": 8000.0, "unit": "GB/s",
+            "frac": measured / 8000.0 if measured else None, "traffic": traffic,
+            "algorithmic_gbps": value / world * bytes_per_unit / 1e9,
+            "l2_hit_rate": hw.get("l2_hit_rate"), "active_lanes": lanes, "valu_issue_frac": issue,
+            "lane_slot_frac": issue * lanes / 64.0 if issue and lanes else None,
+            "counters_stale": stale,
+            "note": "The walk's gathers are dependent (a node's address comes out of the previous node): the kernel "
+                    "is bound by L2 / HBM LATENCY at the occupancy its registers allow, not by bandwidth. achieved "
+                    "= HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, profiles/counters_bvh_*.json) "
+                    "/ the launch's duration in those passes; frac = achieved / the 8 TB/s peak. algorithmic_gbps "
+                    "= 64 B per four-wide node fetched + 64 B per triangle record looked at + 40 B per ray, times "
+                    "the measured rate (what a cache-less walk would move; most of it hits L2). lane_slot_frac = "
+                    "valu_issue_frac x active_lanes / 64: the share of the machine's lane slots doing work. "
+                    "counters_stale: the committed counters are of other sources than this build (fields null)"}
         print(json.dumps(line), flush=True)
     scene.close()
     finish_ranks(world)
@@ -299,7 +324,7 @@ def tree_workload(args):
 def cornell_workload(args):
     import torch
 
-    world, rank, dev, barrier, max_over_ranks = init_ranks(args.rehearse)
+    world, rank, dev, barrier, max_over_ranks = init_ranks(args.rehearse, args.force_dist)
     pkg = graft.load_package()
     abi, api = pkg.abi, pkg.api
     from computer_graphics_amd import parallel
@@ -338,7 +363,7 @@ def cornell_workload(args):
         else:
             # the step's global sample range is split into `world` contiguous sub-ranges; one sum-reduce
             parallel.render_distributed(render, k * global_spp, global_spp, rank, world, step_buf, total,
-                                        via_host=args.rehearse)
+                                        via_host=args.rehearse, always=args.force_dist)
         if k >= args.warmup and rank == 0:
             kernel_ms.append(scene.stats().kernel_ms)  # HIP events around the path kernel on its launch stream
 
@@ -370,7 +395,8 @@ def cornell_workload(args):
         fog_off = SIZE * SIZE * my_spp / (time.perf_counter() - t1)
 
         # hardware counters per launch of this workload, from the committed rocprofv3 --pmc passes
-        hw = load_counters("counters_k_paths.json") or {}
+        hw, stale = load_counters("counters_k_paths.json")
+        hw = hw or {}
         scale = my_spp / hw["spp"] if hw.get("size") == SIZE and hw.get("spp") else None
         traffic = (hw["fetch_bytes_per_launch"] + hw["write_bytes_per_launch"]) * scale if scale else None
 
@@ -401,6 +427,7 @@ def cornell_workload(args):
                          # VALU instructions fill (issue slots used x lanes active), no reference flops involved
                          "executed_lane_op_frac": (hw["valu_issue_frac"] * hw["active_lanes"] / 64.0
                                                    if hw.get("valu_issue_frac") and hw.get("active_lanes") else None),
+                         "counters_stale": stale,
                          "kernel": "k_paths", "kernel_ms": k_ms, "flops_per_launch": flops,
                          "tri_tests": st.tri_tests, "gate_passes": st.gate_passes,
                          "note": "achieved = algorithmic flops of the REFERENCE's scan for this launch (26 per "
@@ -413,10 +440,13 @@ def cornell_workload(args):
                                  "active_lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64), both from the "
                                  "committed rocprofv3 --pmc passes (profiles/counters_k_paths.json), like traffic = "
                                  "HBM bytes per launch (12 bytes written per 16-sample work item; the 22 triangles "
-                                 "stay in the scalar cache and LDS)"},
+                                 "stay in the scalar cache and LDS). counters_stale: that file names the hash of the "
+                                 "sources it was measured on; when this build's differ the counter fields are null"},
         }
         if args.rehearse:
             line["rehearsal"] = "all ranks on one GPU, gloo through the host: not a measurement"
+        if _COLLECTIVES:
+            line["collectives"] = _COLLECTIVES
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(abi, tris, light, params)
         print(json.dumps(line), flush=True)
@@ -441,6 +471,9 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a one-GPU machine: all ranks on GPU 0, gloo instead of RCCL, images reduced through "
                          "the host. Checks the N-rank code path; the line says so and its timings mean nothing")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1: go through torch.distributed all the same (process group over RCCL, barrier, reduce of "
+                         "the image, MAX all-reduce of the timing) -- the N-rank plumbing on a one-GPU machine")
     ap.add_argument("--exact", action="store_true",
                     help="cornell and c4, N > 1: instead of the sum-reduce, pass the image from rank to rank, each folding "
                          "its work items in (parallel.render_chained): the N-GPU image is the 1-GPU image bit for bit")

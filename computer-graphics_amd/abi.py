@@ -24,6 +24,8 @@ MATERIAL_NAMES = {"diffuse": MAT_DIFFUSE, "mirror": MAT_MIRROR, "glass": MAT_GLA
 RNG_MINSTD_PATH, RNG_COUNTER, RNG_MINSTD_GLOBAL = 0, 1, 2
 FLAG_STATS = 1
 SCENE_LINEAR_SCAN = 1  # MIPT_SCENE_LINEAR_SCAN
+MULTI_ALLOW_SHARED_DEVICE = 1  # MIPT_MULTI_ALLOW_SHARED_DEVICE
+MULTI_FRAME_REDUCE, MULTI_FRAME_EXACT = 0, 1  # MIPT_MULTI_FRAME_*
 MAX_DEPTH_LIMIT = 16
 NOALLOC_MAX_BYTES = 32 << 20  # MIPT_NOALLOC_MAX_BYTES
 
@@ -92,6 +94,9 @@ EXPORTS = [
     "mipt_multi_create", "mipt_multi_destroy", "mipt_multi_device_count", "mipt_multi_render_accumulate",
     "mipt_multi_sample_range", "mipt_multi_scene", "mipt_frame_poll",
     "mipt_render_items_dev", "mipt_fold_items_dev", "mipt_multi_render_accumulate_chained", "mipt_multi_item_range",
+    "mipt_multi_create_opts", "mipt_multi_frame_create", "mipt_multi_frame_destroy", "mipt_multi_frame_reset",
+    "mipt_multi_frame_add_samples", "mipt_multi_frame_present", "mipt_multi_frame_read_pixels",
+    "mipt_multi_frame_samples", "mipt_multi_frame_device", "mipt_multi_frame_poll",
 ]
 
 
@@ -150,8 +155,19 @@ def load_library(path=None):
     lib.mipt_fold_items_dev.argtypes = [vp, f32p, vp]
     lib.mipt_get_stats.argtypes = [vp, P(MiptStats)]
     lib.mipt_multi_create.argtypes = [vp, C.c_size_t, vp, C.c_size_t, P(C.c_int), C.c_int, P(vp)]
+    lib.mipt_multi_create_opts.argtypes = [vp, C.c_size_t, vp, C.c_size_t, P(C.c_int), C.c_int, C.c_uint32, P(vp)]
     lib.mipt_multi_destroy.argtypes = [vp]
     lib.mipt_multi_destroy.restype = None
+    lib.mipt_multi_frame_create.argtypes = [vp, C.c_int, C.c_int, C.c_uint32, P(vp)]
+    lib.mipt_multi_frame_destroy.argtypes = [vp]
+    lib.mipt_multi_frame_destroy.restype = None
+    lib.mipt_multi_frame_reset.argtypes = [vp]
+    lib.mipt_multi_frame_add_samples.argtypes = [vp, P(MiptCamera), P(MiptLight), P(MiptParams), C.c_uint32]
+    lib.mipt_multi_frame_present.argtypes = [vp, vp]
+    lib.mipt_multi_frame_read_pixels.argtypes = [vp, vp]
+    lib.mipt_multi_frame_samples.argtypes = [vp]
+    lib.mipt_multi_frame_device.argtypes = [vp]
+    lib.mipt_multi_frame_poll.argtypes = [vp]
     lib.mipt_multi_device_count.argtypes = [vp]
     lib.mipt_multi_scene.argtypes = [vp, C.c_int]
     lib.mipt_multi_scene.restype = vp

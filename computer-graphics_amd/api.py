@@ -338,7 +338,9 @@ class MultiScene:
     splits the sample range over the devices and sums the per-device images with one RCCL reduce
     (mipt_multi_*; replaces the OpenMP loop of main.cpp:121)."""
 
-    def __init__(self, tris, spheres=None, devices=(0,)):
+    def __init__(self, tris, spheres=None, devices=(0,), allow_shared_device=False):
+        """allow_shared_device: a device may be listed more than once (rehearsal of the several-device
+        code on one GPU; relay calls only, RCCL takes one rank per device)."""
         self._lib = abi.load_library()
         tris = np.ascontiguousarray(tris, dtype=abi.TRIANGLE_DTYPE)
         ns = 0 if spheres is None else len(spheres)
@@ -346,8 +348,9 @@ class MultiScene:
             spheres = np.ascontiguousarray(spheres, dtype=abi.SPHERE_DTYPE)
         devs = (C.c_int * len(devices))(*devices)
         h = C.c_void_p()
-        _check(self._lib.mipt_multi_create(_ptr(tris) if len(tris) else None, len(tris),
-                                           _ptr(spheres) if ns else None, ns, devs, len(devices), C.byref(h)))
+        _check(self._lib.mipt_multi_create_opts(_ptr(tris) if len(tris) else None, len(tris),
+                                                _ptr(spheres) if ns else None, ns, devs, len(devices),
+                                                abi.MULTI_ALLOW_SHARED_DEVICE if allow_shared_device else 0, C.byref(h)))
         self._h = h
 
     def close(self):
@@ -385,6 +388,62 @@ class MultiScene:
         _check(self._lib.mipt_multi_render_accumulate_chained(self._h, C.byref(cam), C.byref(light), C.byref(params),
                                                               sample_begin, sample_count, _ptr(accum)))
         return accum
+
+
+class MultiFrame:
+    """Frame on the devices of a MultiScene (mipt_multi_frame_*): exact=False sums the devices' images
+    with one RCCL reduce per add_samples, exact=True relays the image from device to device (the
+    one-GPU frame bit for bit). Close it before its MultiScene."""
+
+    def __init__(self, multi, width, height, exact=False):
+        self._lib = abi.load_library()
+        self.multi, self.width, self.height = multi, width, height
+        h = C.c_void_p()
+        _check(self._lib.mipt_multi_frame_create(multi._h, width, height,
+                                                 abi.MULTI_FRAME_EXACT if exact else abi.MULTI_FRAME_REDUCE, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mipt_multi_frame_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def samples(self):
+        return int(self._lib.mipt_multi_frame_samples(self._h))
+
+    @property
+    def device_index(self):
+        """index into the MultiScene's device list of the device that holds the image"""
+        return int(self._lib.mipt_multi_frame_device(self._h))
+
+    def poll(self):
+        rc = self._lib.mipt_multi_frame_poll(self._h)
+        if rc < 0:
+            _check(rc)
+        return rc == 1
+
+    def reset(self):
+        _check(self._lib.mipt_multi_frame_reset(self._h))
+
+    def add_samples(self, cam, light, params, n):
+        _check(self._lib.mipt_multi_frame_add_samples(self._h, C.byref(cam), C.byref(light), C.byref(params), n))
+
+    def present(self):
+        screen = np.zeros((self.height, self.width), dtype=np.uint32)
+        _check(self._lib.mipt_multi_frame_present(self._h, _ptr(screen)))
+        return screen
+
+    def read_pixels(self):
+        acc = np.zeros((self.width, self.height, 3), dtype=np.float32)
+        _check(self._lib.mipt_multi_frame_read_pixels(self._h, _ptr(acc)))
+        return acc
 
 
 def multi_sample_range(begin, count, rank, n):

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -92,6 +93,9 @@ struct MiptScene {
   uint32_t* d_queue = nullptr;
   float* d_partial = nullptr;
   size_t partial_bytes = 0;
+  // scenes whose path kernel keeps its vertex stacks in global memory (vstack_kind): the stacks of
+  // VSTACK_BLOCKS workgroups at the deepest allowed path, allocated with the scene
+  float4* d_vstack = nullptr;
   // staging memory of the entry points that take HOST pointers (device copies of their arguments):
   // kept and grown on demand, so that a loop over such calls does not allocate and free every time
   void* d_stage = nullptr;
@@ -138,6 +142,7 @@ static void scene_free(MiptScene* s) {
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_queue) (void)hipFree(s->d_queue);
   if (s->d_partial) (void)hipFree(s->d_partial);
+  if (s->d_vstack) (void)hipFree(s->d_vstack);
   if (s->d_stage) (void)hipFree(s->d_stage);
   if (s->d_bvh) (void)hipFree(s->d_bvh);
   if (s->d_big) (void)hipFree(s->d_big);
@@ -657,6 +662,7 @@ static bool make_box_unit(std::vector<QuadRef>& quads, size_t seed, BoxUnit& box
   return false;
 }
 
+constexpr size_t MAX_BOXES_PER_CHUNK = 7;  // bits 26-28 of a chunk's meta word
 // per chunk of 32 triangles: pairs (greedy over consecutive indices) first, then singles
 // `ids` lists the triangles to cover, ascending (all of them for a linear-scan scene, the big ones
 // of a tree scene); mask bit p of chunk c stands for triangle ids[32 c + p].
@@ -714,6 +720,9 @@ static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>
       if (quads[qi].used) continue;
       BoxUnit box;
       std::vector<size_t> members;
+      // the chunk's meta word has three bits for the number of boxes: quads beyond the seventh
+      // box stay pair units
+      if (boxes.size() == MAX_BOXES_PER_CHUNK) break;
       if (!make_box_unit(quads, qi, box, members)) continue;
       for (size_t m : members) quads[m].used = true;
       boxes.push_back(box);
@@ -732,6 +741,9 @@ static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>
     for (const ScanUnit& u : pairs) units[k++] = u;
     for (const ScanUnit& u : singles) units[k++] = u;
     const size_t all_pairs = axis_pairs.size() + pairs.size();
+    // what the fields of the meta word can hold (unit_mask): 5 + 5 + 6 + 3 bits
+    if (axis_pairs.size() > 31 || all_pairs > 31 || all_pairs + singles.size() > 63 || boxes.size() > MAX_BOXES_PER_CHUNK)
+      throw std::length_error("scan-unit counts of a chunk do not fit its meta word");
     // the counts of the chunk (unit_mask); a box keeps its meta where a scan unit does
     const uint32_t counts = ((uint32_t)axis_pairs.size() << 10) | ((uint32_t)all_pairs << 15) |
                             ((uint32_t)(all_pairs + singles.size()) << 20) | ((uint32_t)boxes.size() << 26);
@@ -787,7 +799,33 @@ static void make_tri_recs(const MiptTriangle* tris, size_t n_tris, std::vector<T
   }
 }
 
+static int scene_kind(const MiptScene* s) {
+  if (s->d.bvh) return SCENE_BVH;
+  const int n_prims = s->d.n_tris + s->d.n_spheres;
+  if (n_prims <= LDS_TABLE_MAX) return SCENE_LINEAR_LDS;
+  // a primitive index must fit the vertex stack's tag below the two marks at the top of its range
+  return n_prims < TAG16_MAX_PRIMS ? SCENE_LINEAR : SCENE_LINEAR_BIG;
+}
+
+// Persistent grid of the path kernel for scenes with global vertex stacks: what fits the chip at the
+// kernel's occupancy (256 CUs x 5 workgroups at most), so that the stacks have a fixed, modest size:
+// 2 planes x 2 buffers x (MIPT_MAX_DEPTH_LIMIT + 1) levels x 16 bytes per lane = 357 MB.
+constexpr unsigned VSTACK_BLOCKS = 1280;
+static inline size_t vstack_bytes(size_t lanes, size_t max_depth) { return 2 * 2 * (max_depth + 1) * lanes * sizeof(float4); }
+
+static int scene_create_scan(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
+                             size_t n_spheres, int device, uint32_t options, MiptScene* s);
 static int scene_create_impl(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
+                             size_t n_spheres, int device, uint32_t options, MiptScene* s) {
+  const int rc = scene_create_scan(tris, n_tris, spheres, n_spheres, device, options, s);
+  if (rc != MIPT_OK) return rc;
+  if (vstack_kind(scene_kind(s)))
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_vstack),
+                      vstack_bytes((size_t)VSTACK_BLOCKS * BLOCK, MIPT_MAX_DEPTH_LIMIT)));
+  return MIPT_OK;
+}
+
+static int scene_create_scan(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
                              size_t n_spheres, int device, uint32_t options, MiptScene* s) {
   s->device = device;
   HIP_TRY(hipSetDevice(device));
@@ -1177,15 +1215,14 @@ static void fill_args(PathArgs& a, const MiptScene* s, const MiptCamera* cam, co
   a.stats = s->d_stats;
 }
 
-static int scene_kind(const MiptScene* s) {
-  if (s->d.bvh) return SCENE_BVH;
-  return (s->d.n_tris + s->d.n_spheres <= LDS_TABLE_MAX) ? SCENE_LINEAR_LDS : SCENE_LINEAR;
-}
-
 // dynamic LDS of the path kernel: the per-lane vertex stack, then (small scenes) the record tables
 static size_t lds_bytes(const MiptScene* s, const MiptParams* p, PathArgs& a) {
   // the vertex stack(s) of tags, then the sphere normals beside them, then the record tables
   const int kind = scene_kind(s);
+  if (vstack_kind(kind)) {  // vertex stacks in global memory: no dynamic LDS at all
+    a.lds_sph_off = a.lds_table_off = 0;
+    return 0;
+  }
   const size_t tag_size = kind == SCENE_LINEAR_LDS ? 1 : kind == SCENE_LINEAR ? 2 : 4;
   const size_t n_stacks = paths_deferred(kind, s->d.n_spheres) ? 2 : 1;
   size_t bytes = n_stacks * (size_t)p->max_depth * BLOCK * tag_size;
@@ -1216,6 +1253,7 @@ static void launch_paths(const MiptScene* s, const PathArgs& a, dim3 grid, size_
   switch (scene_kind(s)) {
     case SCENE_BVH: launch_paths_kind<LIST, SCENE_BVH>(a, grid, lds, st); break;
     case SCENE_LINEAR: launch_paths_kind<LIST, SCENE_LINEAR>(a, grid, lds, st); break;
+    case SCENE_LINEAR_BIG: launch_paths_kind<LIST, SCENE_LINEAR_BIG>(a, grid, lds, st); break;
     default: launch_paths_kind<LIST, SCENE_LINEAR_LDS>(a, grid, lds, st); break;
   }
 }
@@ -1277,7 +1315,14 @@ static int render_launch(MiptScene* s, const MiptCamera* cam, const MiptLight* l
   a.partial = scr.sums;
   // enough resident waves to fill the chip at any occupancy; every lane loops over the queue
   const uint64_t batches = r.n_items / 64u;
-  const unsigned grid = (unsigned)(batches / 4u + 1u < PERSISTENT_BLOCKS ? batches / 4u + 1u : PERSISTENT_BLOCKS);
+  const bool gstack = vstack_kind(scene_kind(s));
+  const unsigned max_grid = gstack ? VSTACK_BLOCKS : PERSISTENT_BLOCKS;
+  const unsigned grid = (unsigned)(batches / 4u + 1u < max_grid ? batches / 4u + 1u : max_grid);
+  if (gstack) {
+    a.vstack = s->d_vstack;
+    a.vstride = VSTACK_BLOCKS * BLOCK;
+    a.vplane = 2u * (uint32_t)(p->max_depth + 1) * a.vstride;
+  }
   HIP_TRY(hipMemsetAsync(scr.queue, 0, sizeof(uint32_t), st));
   const bool stats = (p->flags & MIPT_FLAG_STATS) != 0;
   if (stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, (ST_COUNT + PF_COUNT) * sizeof(unsigned long long), st));
@@ -1294,9 +1339,11 @@ static int render_launch(MiptScene* s, const MiptCamera* cam, const MiptLight* l
                        d_accum_rgb);
     HIP_TRY(hipGetLastError());
   }
-  if (timed) s->timed = true;
-  s->stats_valid = stats;
-  s->last_paths = (uint64_t)p->width * p->height * sample_count;
+  if (timed) {  // the entry point that allocates nothing leaves what mipt_get_stats reports alone
+    s->timed = true;
+    s->stats_valid = stats;
+    s->last_paths = (uint64_t)p->width * p->height * sample_count;
+  }
   return MIPT_OK;
 }
 
@@ -1363,6 +1410,12 @@ extern "C" int mipt_fold_items_dev(MiptScene* s, float* d_accum_rgb, void* strea
   return scratch_release(s, st);
 }
 
+// For the library's multi-GPU driver: forget the item sums of a mipt_render_items_dev that will not be
+// folded (a later step of the same call failed), so that the scene accepts render calls again.
+extern "C" void mipt_internal_discard_items(MiptScene* s) {
+  if (s) s->items_pending = false;
+}
+
 // The same call for callers that must not allocate (code under HIP graph capture, tight serving
 // loops): queue head and item sums live in the file-scope array `scratch` of this device, whose
 // address noalloc_setup() fetched at scene creation. No hipMalloc / hipFree, no events.
@@ -1371,6 +1424,8 @@ extern "C" int mipt_render_accumulate_noalloc_dev(MiptScene* s, const MiptCamera
                                                   uint32_t sample_count, float* d_accum_rgb, void* stream) {
   int rc = render_check(s, cam, light, p, sample_begin, sample_count, d_accum_rgb);
   if (rc != MIPT_OK) return rc;
+  if (p->flags & MIPT_FLAG_STATS)  // the counters are scene scratch, ordered by events this call does not use
+    return fail(MIPT_E_INVALID, "mipt_render_accumulate_noalloc_dev: MIPT_FLAG_STATS is not available here");
   if (sample_count == 0) return MIPT_OK;
   RenderShape r;
   rc = render_shape(p, sample_count, r);
@@ -1422,7 +1477,7 @@ extern "C" int mipt_trace_paths(MiptScene* s, const MiptCamera* cam, const MiptL
     if (px[i] < 0 || px[i] >= p->width || py[i] < 0 || py[i] >= p->height)
       return fail(MIPT_E_INVALID, "mipt_trace_paths: path %zu pixel (%d, %d) outside the image", i, px[i], py[i]);
   HIP_TRY(hipSetDevice(s->device));
-  DevBuf dx, dy, ds, drgb, dcnt;
+  DevBuf dx, dy, ds, drgb, dcnt, dvs;
   HIP_TRY(dx.alloc(n_paths * 4)); HIP_TRY(dy.alloc(n_paths * 4)); HIP_TRY(ds.alloc(n_paths * 4));
   HIP_TRY(drgb.alloc(n_paths * 12)); HIP_TRY(dcnt.alloc(n_paths * 8));
   HIP_TRY(hipMemcpy(dx.p, px, n_paths * 4, hipMemcpyHostToDevice));
@@ -1434,6 +1489,18 @@ extern "C" int mipt_trace_paths(MiptScene* s, const MiptCamera* cam, const MiptL
   a.n_paths = (uint32_t)n_paths;
   a.rgb = drgb.as<float>();
   a.counts = dcnt.as<uint32_t>();
+  if (vstack_kind(scene_kind(s))) {
+    // one lane per listed path: the scene's vertex stacks if they are large enough, else a temporary
+    const size_t lanes = (size_t)grid_for(n_paths) * BLOCK;
+    if (lanes > 0x7FFFFFFFull / (2u * (MIPT_MAX_DEPTH_LIMIT + 1))) return fail(MIPT_E_INVALID, "mipt_trace_paths: too many paths");
+    a.vstack = s->d_vstack;
+    if (lanes > (size_t)VSTACK_BLOCKS * BLOCK) {
+      HIP_TRY(dvs.alloc(vstack_bytes(lanes, (size_t)p->max_depth)));
+      a.vstack = dvs.as<float4>();
+    }
+    a.vstride = (uint32_t)lanes;
+    a.vplane = 2u * (uint32_t)(p->max_depth + 1) * a.vstride;
+  }
   const bool stats = (p->flags & MIPT_FLAG_STATS) != 0;
   if (s->busy_valid) HIP_TRY(hipEventSynchronize(s->ev_busy));  // the counters are scene scratch too
   if (stats) HIP_TRY(hipMemset(s->d_stats, 0, (ST_COUNT + PF_COUNT) * sizeof(unsigned long long)));

@@ -534,7 +534,10 @@ struct BvhRay {
   uint32_t n_nodes, n_leaves;  // work counters (dead code unless the caller reads them)
 };
 
-__device__ __forceinline__ BvhRay bvh_ray(const DeviceScene& sc, V4 o, V4 d) {
+// (the scene arguments of the walk's functions are POINTERS to a DeviceScene, in whatever address space
+// the caller has it: a kernel that is short of scalar registers hands in its argument block and the
+// fields are fetched where they are used, see late_args() in mipt_kernels.hpp)
+__device__ __forceinline__ BvhRay bvh_ray(float scene_scale, V4 o, V4 d) {
   BvhRay r;
   r.o = o; r.d = d;
   r.px = -d.x; r.py = -d.y; r.pz = -d.z;
@@ -544,19 +547,23 @@ __device__ __forceinline__ BvhRay bvh_ray(const DeviceScene& sc, V4 o, V4 d) {
   r.Dm = sane ? Dabs : __builtin_inff();
   // absolute slack on ray parameters: the determinant ratio of a triangle the origin lies on is
   // rounding noise of about 2^-23 (|o| + |v|) / (|d| cos(angle to the normal))
-  r.delta = sane ? 0.0001220703125f * (sc.scale + Om) / Dabs : 0.f;  // 2^-13
+  // (hardware reciprocals, within 1 ulp: delta is an order-of-magnitude slack, and an inverse direction
+  // off by 2^-23 moves a box plane by less than the rounding of the slab distances themselves, far
+  // inside the padding of the leaf boxes; a subnormal component counts as zero: +-inf like 1 / 0.
+  // The path kernel calls this in every iteration of a walk: four IEEE divisions cost ~50 instructions)
+  r.delta = sane ? (0.0001220703125f * (scene_scale + Om)) * __builtin_amdgcn_rcpf(Dabs) : 0.f;  // 2^-13
   r.n_nodes = 0; r.n_leaves = 0;
   r.oo = {o.x, o.y, o.z};
-  r.inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+  r.inv = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)};
   return r;
 }
 
 // could the reference accept this triangle at all? intersections.cpp:25 with min = FLT_MAX, :27
 // FILTER = false: the caller has run the candidate filter on this triangle already (scan units)
-template <bool FILTER = true>
-__device__ __forceinline__ bool bvh_leaf(const DeviceScene& sc, const BvhRay& r, int i, float& t, float& z,
+template <bool FILTER = true, typename SP>
+__device__ __forceinline__ bool bvh_leaf(SP sc, const BvhRay& r, int i, float& t, float& z,
                                          float& x1, float& x2) {
-  const TriRec T = sc.tris[i];
+  const TriRec T = sc->tris[i];
   if (FILTER && !tri_candidate(&T, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.Dm)) return false;
   float x0;
   tri_eval(&T, r.o.x, r.o.y, r.o.z, r.px, r.py, r.pz, t, x0, x1, x2);
@@ -616,9 +623,10 @@ __device__ __forceinline__ void bvh_take(BvhTrav& T, BvhMem& M, const BvhRay& r,
   }
 }
 
-__device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, const DeviceScene& sc, BvhRay& r, bool shadow,
+template <typename SP>
+__device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, SP sc, BvhRay& r, bool shadow,
                                           float max_t) {
-  T.cur = sc.bvh_root;
+  T.cur = sc->bvh_root;
   T.pend = BVH_DONE;
   T.sp = 0; T.n_list = 0;
   T.best = {-1, 0.f, 0.f, 0.f, 0.f};
@@ -630,18 +638,22 @@ __device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, const DeviceSce
   // box would swallow every ray; tested up front it also gives the walk its first pruning bound.
   // Filtered like the linear scan does it (scan units over the big list: walls come in coplanar
   // pairs), candidates then go through the reference's test in index order.
-  for (int base = 0; base < sc.n_big; base += 32) {
-    uint32_t mask = unit_mask(sc.units + base, r.o, r.d, r.Dm);
+  for (int base = 0; base < sc->n_big; base += 32) {
+    uint32_t mask = unit_mask(sc->units + base, r.o, r.d, r.Dm);
     r.n_leaves += (uint32_t)__popc(mask);
     while (mask != 0 && !(T.redo || T.hit)) {
-      const int i = sc.big_ids[base + __ffs((int)mask) - 1];
+      const int i = sc->big_ids[base + __ffs((int)mask) - 1];
       mask &= mask - 1u;
       float t, z, x1, x2;
       if (bvh_leaf<false>(sc, r, i, t, z, x1, x2)) bvh_take(T, M, r, shadow, max_t, i, t, z, x1, x2);
     }
   }
   // a big triangle may have ended the query (any-hit found, or redo) before the tree had a say
-  T.cur = (T.redo || T.hit) ? BVH_DONE : sc.bvh_root;
+  // (Measured and dropped: a test of the ray against the bounds of the whole tree here, which ends
+  // three quarters of a room-with-a-mesh scene's queries before any node is fetched. The wave still
+  // waits for the lanes that do walk, so nothing is gained: -1 ... -3 % paths/s on three scenes; and
+  // letting the walkers wait until 16 ... 48 lanes have a walk to do lost 3 ... 20 %.)
+  T.cur = (T.redo || T.hit) ? BVH_DONE : sc->bvh_root;
 }
 
 // Each round the wave does ONE kind of work, a node step or a leaf test, whichever more of its
@@ -656,8 +668,8 @@ __device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, const DeviceSce
 // of walking on. An any-hit walk most likely ENDS at its next leaf test, so the nodes it steps through
 // meanwhile are mostly wasted (10^6-triangle soup: +15 % any-hit rays/s, 102 k mesh +4 %); a closest-hit
 // walk has to visit them anyway, and in the path kernel, where the two kinds share waves, waiting lost 1-4 %.
-template <int KEEP_NUM = BVH_KEEP_NUM, int KEEP_DEN = BVH_KEEP_DEN, bool SET_ASIDE = true, typename STK>
-__device__ __forceinline__ void bvh_burst(BvhTrav& T, BvhMem& M, const STK& stack, const DeviceScene& sc,
+template <int KEEP_NUM = BVH_KEEP_NUM, int KEEP_DEN = BVH_KEEP_DEN, bool SET_ASIDE = true, typename STK, typename SP>
+__device__ __forceinline__ void bvh_burst(BvhTrav& T, BvhMem& M, const STK& stack, SP sc,
                                           const BvhNode* __restrict__ nodes, BvhRay& r, bool shadow, float max_t,
                                           uint32_t& overflow) {
   const int entered = __popcll(__ballot(T.cur != BVH_DONE));
@@ -721,7 +733,8 @@ __device__ __forceinline__ void bvh_finish(const BvhTrav& T, const BvhMem& M, bo
 // The same without any assumption about distances: the reference's scan accepts, after triangle
 // `after`, the lowest-numbered triangle that passes its test against the current limit; each
 // pass walks every box the ray touches to find that triangle, until a pass finds none.
-__device__ __forceinline__ void bvh_closest_exhaustive(const DeviceScene& sc, const BvhNode* __restrict__ nodes,
+template <typename SP>
+__device__ __forceinline__ void bvh_closest_exhaustive(SP sc, const BvhNode* __restrict__ nodes,
                                                        BvhRay& r, HitAcc& h, uint32_t& overflow) {
   int after = -1;
   for (;;) {
@@ -729,14 +742,14 @@ __device__ __forceinline__ void bvh_closest_exhaustive(const DeviceScene& sc, co
     float bz = 0.f, b1 = 0.f, b2 = 0.f;
     int stack[BVH_STACK];
     int sp = 0;
-    for (int b = 0; b < sc.n_big; ++b) {
-      const int i = sc.big_ids[b];
+    for (int b = 0; b < sc->n_big; ++b) {
+      const int i = sc->big_ids[b];
       float t, z, x1, x2;
       if (i > after && i < best && bvh_leaf(sc, r, i, t, z, x1, x2) && t <= h.lim) {
         best = i; bz = z; b1 = x1; b2 = x2;
       }
     }
-    int cur = sc.bvh_root;
+    int cur = sc->bvh_root;
     for (;;) {
       if (cur == BVH_DONE) break;
       if (cur < 0) {

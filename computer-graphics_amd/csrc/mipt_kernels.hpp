@@ -55,6 +55,13 @@ struct PathArgs {
   uint32_t n_paths;
   float* rgb;
   uint32_t* counts;
+  // Scenes whose vertex stacks live in global memory (vstack_kind): two planes of 16-byte entries,
+  // entry (buffer b, level k) of lane g at ((b * (max_depth + 1) + k) * vstride + g); plane 0 the
+  // vertex's normal, plane 1 (vplane entries further) its colour and kind. Level max_depth of plane 1
+  // holds the colour and material of the path's terminal vertex.
+  float4* vstack;
+  uint32_t vstride;        // lanes of the launch (grid * BLOCK)
+  uint32_t vplane;         // 2 * (max_depth + 1) * vstride
   uint32_t lds_sph_off;    // dword offset of the sphere normals beside the vertex stack in dynamic LDS
   uint32_t lds_table_off;  // SCENE_LINEAR_LDS: dword offset of the record tables in dynamic LDS
   unsigned long long* stats;  // ST_COUNT device counters, STATS builds only
@@ -119,16 +126,31 @@ enum ScanMode { SCAN_LITERAL = 0, SCAN_FAST = 1, SCAN_TWO_PHASE = 2 };
 // Kinds of scene the path kernel is instantiated for: linear scan with the triangle and shading
 // records staged in LDS (scenes of at most LDS_TABLE_MAX primitives), linear scan from global
 // memory, LBVH.
-enum SceneKind { SCENE_LINEAR_LDS = 0, SCENE_LINEAR = 1, SCENE_BVH = 2 };
+enum SceneKind { SCENE_LINEAR_LDS = 0, SCENE_LINEAR = 1, SCENE_BVH = 2, SCENE_LINEAR_BIG = 3 };
 constexpr int LDS_TABLE_MAX = 64;
 // The vertex stack holds primitive indices: a byte each for the scenes whose tables fit LDS (at most
-// 64 primitives), 16 bits for the other linear scenes (< 256 triangles + at most 4096 spheres).
+// 64 primitives), 16 bits for linear scenes of fewer than TAG16_MAX_PRIMS primitives (the two marks
+// TAG_GLASS / TAG_FOG sit at the top of the 16-bit range), 32 bits for everything else: tree
+// scenes, and the linear scan forced onto a large scene (SCENE_LINEAR_BIG).
+constexpr int TAG16_MAX_PRIMS = 0xFFFD;
 template <int KIND> struct TagType { typedef uint32_t T; };
 template <> struct TagType<SCENE_LINEAR_LDS> { typedef uint8_t T; };
 template <> struct TagType<SCENE_LINEAR> { typedef uint16_t T; };
 // Linear-scan scenes without spheres finish their lit paths in batches (see k_paths): two vertex
 // stacks, two terminal records and two radiance sums per lane.
-__host__ __device__ inline bool paths_deferred(int kind, int n_spheres) { return kind != SCENE_BVH && n_spheres == 0; }
+// Scenes too large for 16-bit tags (a tree, or the linear scan forced onto a big scene) keep their
+// vertex stacks in global memory as RECORDS -- the vertex's normal, colour and kind, 32 bytes -- so
+// the completion needs no index into the scene and no second stack of sphere normals, and the LDS
+// holds two terminal records and two sums per lane whatever the scene's size: they always finish in
+// batches.
+#ifndef MIPT_TREE_VSTACK
+#define MIPT_TREE_VSTACK 0
+#endif
+__host__ __device__ inline bool vstack_kind(int kind) { return (MIPT_TREE_VSTACK && kind == SCENE_BVH) || kind == SCENE_LINEAR_BIG; }
+__host__ __device__ inline bool paths_deferred(int kind, int n_spheres) {
+  return vstack_kind(kind) || (kind != SCENE_BVH && n_spheres == 0);
+}
+constexpr uint32_t VK_DIFFUSE = 0u, VK_GLASS = 1u, VK_FOG = 2u;  // kinds of a vertex record
 
 #ifndef MIPT_SCAN_MODE
 #define MIPT_SCAN_MODE 2
@@ -195,14 +217,14 @@ __device__ __forceinline__ void scene_query(const DeviceScene& sc, V4 o, V4 d, b
     return;
   }
   // blocking form of the resumable walk: every lane stays until its own ray is done
-  BvhRay r = bvh_ray(sc, o, d);
+  BvhRay r = bvh_ray(sc.scale, o, d);
   BvhTrav T;
   BvhMem M;
-  bvh_begin(T, M, sc, r, shadow, h.lim);
-  while (T.cur != BVH_DONE) bvh_burst(T, M, StackScratch{M.stack}, sc, sc.bvh, r, shadow, h.lim, overflow);
+  bvh_begin(T, M, &sc, r, shadow, h.lim);
+  while (T.cur != BVH_DONE) bvh_burst(T, M, StackScratch{M.stack}, &sc, sc.bvh, r, shadow, h.lim, overflow);
   if (T.redo) {
     redo++;
-    bvh_closest_exhaustive(sc, sc.bvh, r, h, overflow);
+    bvh_closest_exhaustive(&sc, sc.bvh, r, h, overflow);
   } else {
     bvh_finish(T, M, shadow, h);
   }
@@ -396,10 +418,10 @@ __global__ __launch_bounds__(BLOCK) MIPT_BATCH_OCC void k_bvh_batch(DeviceScene 
         if (!have && rank < avail) {
           my = res_next + rank;
           const float4 of = origin[my], df = dir[my];
-          r = bvh_ray(sc, {of.x, of.y, of.z, of.w}, {df.x, df.y, df.z, df.w});
+          r = bvh_ray(sc.scale, {of.x, of.y, of.z, of.w}, {df.x, df.y, df.z, df.w});
           lim0 = SHADOW ? max_t[my] : 3.402823466e+38f;
           if (order) my = order[my];  // from here on `my` is only where the result goes
-          bvh_begin(T, M, sc, r, SHADOW, lim0);
+          bvh_begin(T, M, &sc, r, SHADOW, lim0);
           have = true;
         }
         const unsigned long long n_need = (unsigned long long)__popcll(need);
@@ -409,12 +431,12 @@ __global__ __launch_bounds__(BLOCK) MIPT_BATCH_OCC void k_bvh_batch(DeviceScene 
     if (!__any(have)) break;  // every lane idle: the queue has run dry
     if (have) {
       // refills are cheap here (two loads and the big-triangle filter): leave the walk when half is done
-      bvh_burst<1, 2, !SHADOW>(T, M, stk, sc, sc.bvh, r, SHADOW, lim0, overflow);
+      bvh_burst<1, 2, !SHADOW>(T, M, stk, &sc, sc.bvh, r, SHADOW, lim0, overflow);
       if (T.cur == BVH_DONE) {
         HitAcc h;
         h.set_lim(lim0);
         h.idx = SHADOW ? 0 : -1; h.by = 0.f; h.bz = 0.f;
-        if (T.redo) bvh_closest_exhaustive(sc, sc.bvh, r, h, overflow);
+        if (T.redo) bvh_closest_exhaustive(&sc, sc.bvh, r, h, overflow);
         else bvh_finish(T, M, SHADOW, h);
         if (SHADOW) {
           occluded[my] = (uint8_t)h.idx;
@@ -523,9 +545,13 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   // Linear-scan scenes without spheres use both sets (deferred completion, below), the others one.
   typedef typename TagType<KIND>::T TagT;
   constexpr uint32_t TAGV_GLASS = (uint32_t)(TagT)TAG_GLASS, TAGV_FOG = (uint32_t)(TagT)TAG_FOG;
-  constexpr bool DEFER_KIND = KIND != SCENE_BVH;
+  constexpr bool GSTACK = (MIPT_TREE_VSTACK && KIND == SCENE_BVH) || KIND == SCENE_LINEAR_BIG;  // vstack_kind(KIND)
+  constexpr bool DEFER_KIND = GSTACK || KIND != SCENE_BVH;
   const bool defer = paths_deferred(KIND, a.sc.n_spheres);  // wave-uniform
   __shared__ float park[DEFER_KIND ? 22 : 11][BLOCK];
+  const size_t gtid = (size_t)blockIdx.x * BLOCK + tid;
+  // entry of the vertex stack the running path writes next (GSTACK): buffer js & JS_CUR, level = stack height
+#define MIPT_VTOP() (((size_t)(((js & JS_CUR) ? P.max_depth + 1 : 0) + (ds & 0xFFu))) * a.vstride + gtid)
   bool have = false;
   if (LIST) {
     list_i = (size_t)blockIdx.x * BLOCK + tid;
@@ -589,6 +615,8 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
     shade_tab = reinterpret_cast<const ShadeRec*>(tab);
     tri_tab = reinterpret_cast<const TriRec*>(tab + n_shade_dw);
   }
+  // A field of the scene: tree scenes fetch it from the argument block at the point of use (see late_args)
+#define MIPT_SC(f) (BVH ? late_args()->sc.f : a.sc.f)
   Prof prof{};
 #ifdef MIPT_PROFILE_SECTIONS
   __shared__ uint32_t prof_lds[PF_COUNT];
@@ -694,16 +722,26 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
     // ---- one ray/scene query: closestIntersection, or existsIntersection for a shadow ray
     const float lim0 = shadow ? shadow_max : 3.402823466e+38f;
     if (BVH) {
-      BvhRay r = bvh_ray(a.sc, o, d);  // o, d stay put while the lane walks
-      if (!walking) { bvh_begin(trav, trav_mem, a.sc, r, shadow, lim0); walking = true; }
-      bvh_burst(trav, trav_mem, StackLds{bvh_lds_stack + tid, trav_mem.stack}, a.sc, a.sc.bvh, r, shadow, lim0, overflow);
+      // (the scene's fields are fetched from the argument block where the walk uses them: held in scalar
+      // registers from the kernel's entry on they crowd out the loop's own and are spilled)
+      BvhRay r = bvh_ray(late_args()->sc.scale, o, d);  // o, d stay put while the lane walks
+      if (!walking) { bvh_begin(trav, trav_mem, &late_args()->sc, r, shadow, lim0); walking = true; }
+      prof.mark(PF_PHASE1);
+      {
+        const PathArgs MIPT_CONST* kb = late_args();
+        bvh_burst(trav, trav_mem, StackLds{bvh_lds_stack + tid, trav_mem.stack}, &kb->sc, kb->sc.bvh, r, shadow, lim0, overflow);
+      }
       n_tests = r.n_leaves; n_nodes = r.n_nodes;
+      prof.mark(PF_PHASE2);
       if (trav.cur == BVH_DONE) {
         walking = false;
         ready = true;
         h.set_lim(lim0);
         h.idx = shadow ? 0 : -1;
-        if (trav.redo) { redo = 1; bvh_closest_exhaustive(a.sc, a.sc.bvh, r, h, overflow); n_tests = r.n_leaves; n_nodes = r.n_nodes; }
+        if (trav.redo) {
+          const PathArgs MIPT_CONST* kx = late_args();
+          redo = 1; bvh_closest_exhaustive(&kx->sc, kx->sc.bvh, r, h, overflow); n_tests = r.n_leaves; n_nodes = r.n_nodes;
+        }
         else bvh_finish(trav, trav_mem, shadow, h);
       }
       if (STATS) { st[ST_TESTS] += n_tests; st[ST_BVH_REDO] += redo; st[ST_BVH_OVERFLOW] += overflow; st[ST_BVH_NODES] += n_nodes; }
@@ -728,19 +766,20 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
     } else {
       V4 pos = {0, 0, 0, 0}, nrm = {0, 0, 0, 0};
       bool sphere_hit = false;
-      for (int j = 0; j < a.sc.n_spheres; ++j) {  // intersections.cpp:39-52
+      const int n_sph = MIPT_SC(n_spheres);
+      for (int j = 0; j < n_sph; ++j) {  // intersections.cpp:39-52
         if (STATS) st[ST_SPHERE]++;
-        if (sphere_test(a.sc.spheres[j], o, d, h.lim, pos, nrm)) {
-          h.idx = a.sc.n_tris + j;
+        if (sphere_test(MIPT_SC(spheres)[j], o, d, h.lim, pos, nrm)) {
+          h.idx = MIPT_SC(n_tris) + j;
           sphere_hit = true;
         }
       }
       if (h.idx < 0) {
         path_done = true;  // pathtracer.cpp:74-75: miss, colour stays 0
       } else {
-        const ShadeRec sh = shade_tab[h.idx];
+        const ShadeRec sh = (BVH ? MIPT_SC(shade) : shade_tab)[h.idx];
         if (!sphere_hit) {
-          const TriRec T = tri_tab[h.idx];
+          const TriRec T = (BVH ? MIPT_SC(tris) : tri_tab)[h.idx];
           pos.x = (T.v0x + h.by * T.e1x) + h.bz * T.e2x;  // intersections.cpp:29
           pos.y = (T.v0y + h.by * T.e1y) + h.bz * T.e2y;
           pos.z = (T.v0z + h.by * T.e1z) + h.bz * T.e2z;
@@ -801,6 +840,9 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           park[t0 + 0][tid] = d.x; park[t0 + 1][tid] = d.y; park[t0 + 2][tid] = d.z; park[t0 + 3][tid] = d.w;  // last segment
           park[t0 + 4][tid] = m; park[t0 + 5][tid] = r;
           park[t0 + 6][tid] = __uint_as_float(medium ? TERMINAL_IN_MEDIUM : (uint32_t)h.idx);
+          if (GSTACK && !medium)  // what the completion needs of the primitive (pathtracer.cpp:88-93)
+            a.vstack[((size_t)(((js & JS_CUR) ? P.max_depth + 1 : 0) + P.max_depth)) * a.vstride + gtid + a.vplane] =
+                make_float4(sh.r, sh.g, sh.b, __uint_as_float(sh.material));
           nd = vecr; renorm = true;  // Ray ctor normalises again (ray.h:11-12)
           shadow_max = r;
           shadow = true;
@@ -818,7 +860,10 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
           sc_r = sqrtf(s2 < 0.f ? 0.f : s2);
           sc_phi = 6.28318530718f * u2;
           need_sc = true; scatter = true;
-          tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + (ds & 0xFFu))) * BLOCK + tid] = (TagT)TAG_FOG;
+          if (GSTACK)
+            a.vstack[MIPT_VTOP() + a.vplane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(VK_FOG));
+          else
+            tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + (ds & 0xFFu))) * BLOCK + tid] = (TagT)TAG_FOG;
           ds += 0x101u;  // sp++, depth++
           prof.mark(PF_SCATTER);
         } else {
@@ -835,8 +880,15 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
             sc_r = sqrtf(1.0f - sc_y * sc_y);
             sc_phi = (float)((2 * 3.14) * (double)ub);
             need_sc = true;
-            tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + (ds & 0xFFu))) * BLOCK + tid] = (TagT)h.idx;
-            if (sphere_hit) {
+            if (GSTACK) {
+              // the record: the normal and the colour the unwind multiplies by (pathtracer.cpp:17-18)
+              const size_t vi = MIPT_VTOP();
+              a.vstack[vi] = make_float4(nrm.x, nrm.y, nrm.z, nrm.w);
+              a.vstack[vi + a.vplane] = make_float4(sh.r, sh.g, sh.b, __uint_as_float(VK_DIFFUSE));
+            } else {
+              tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + (ds & 0xFFu))) * BLOCK + tid] = (TagT)h.idx;
+            }
+            if (!GSTACK && sphere_hit) {
               float* q = sph_n + ((size_t)(ds & 0xFFu) * BLOCK + tid) * 4;
               q[0] = nrm.x; q[1] = nrm.y; q[2] = nrm.z; q[3] = nrm.w;
             }
@@ -876,7 +928,10 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
               nd = add4(d, scale4(n, cost1 * 2.0f));
             }
             renorm = true;
-            tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + (ds & 0xFFu))) * BLOCK + tid] = (TagT)TAG_GLASS;
+            if (GSTACK)
+              a.vstack[MIPT_VTOP() + a.vplane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(VK_GLASS));
+            else
+              tags[((size_t)(((js & JS_CUR) ? P.max_depth : 0) + (ds & 0xFFu))) * BLOCK + tid] = (TagT)TAG_GLASS;
             ds += 0x101u;
             prof.mark(PF_GLASS);
           } else if (mat == MIPT_MAT_SPECULAR) {
@@ -955,8 +1010,30 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
         const float light_col[3] = {kc->light_col[0], kc->light_col[1], kc->light_col[2]};
         const uint32_t light_gray = kc->light_gray;
         const float glass_weight = kc->p.glass_weight, diffuse_weight = kc->p.diffuse_weight, fog_albedo = kc->p.fog_albedo;
+        // Global vertex stacks: the loads of the terminal vertex' colour and of the four deepest vertex
+        // records are issued together, before anything waits (a level at a time, the unwind paid one
+        // memory latency per level of the longest job).
+        const float4* vsn = nullptr;
+        const float4* vsc = nullptr;
+        float4 tc = {0.f, 0.f, 0.f, 0.f}, qc0 = tc, qc1 = tc, qc2 = tc, qc3 = tc, qn0 = tc, qn1 = tc, qn2 = tc, qn3 = tc;
+        if (GSTACK) {
+          vsn = a.vstack + ((size_t)(b * (P.max_depth + 1))) * a.vstride + gtid;  // level k at vsn[k * vstride]
+          vsc = vsn + a.vplane;
+          const int k = job_sp - 1;
+          const size_t i0 = (size_t)(k > 0 ? k : 0) * a.vstride, i1 = (size_t)(k > 1 ? k - 1 : 0) * a.vstride;
+          const size_t i2 = (size_t)(k > 2 ? k - 2 : 0) * a.vstride, i3 = (size_t)(k > 3 ? k - 3 : 0) * a.vstride;
+          tc = vsc[(size_t)P.max_depth * a.vstride];
+          qc0 = vsc[i0]; qc1 = vsc[i1]; qc2 = vsc[i2]; qc3 = vsc[i3];
+          qn0 = vsn[i0]; qn1 = vsn[i1]; qn2 = vsn[i2]; qn3 = vsn[i3];
+        }
         if (tprim != TERMINAL_IN_MEDIUM) {
-          const ShadeRec sh = shade_tab[tprim];
+          struct { float r, g, b; uint32_t material; } sh;
+          if (GSTACK) {
+            sh.r = tc.x; sh.g = tc.y; sh.b = tc.z; sh.material = __float_as_uint(tc.w);
+          } else {
+            const ShadeRec rec = (BVH ? MIPT_SC(shade) : shade_tab)[tprim];
+            sh.r = rec.r; sh.g = rec.g; sh.b = rec.b; sh.material = rec.material;
+          }
           cr = (light_col[0] * m) / den;
           if (light_gray) {
             cg = cr; cb = cr;
@@ -978,20 +1055,42 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
         // (one straight body for the three kinds of vertex, selected by the tag: as three nested
         // per-lane branches a level cost ~30 scalar instructions for the execution masks, and the jobs of
         // a flush are of mixed kinds at every level anyway. x * 1.0f is x.)
+        // glass: (c * 1) * weight (pathtracer.cpp:62); fog: c * albedo; diffuse, with the direction of
+        // the last segment: (((c * colour) * dn) * 1) * weight (pathtracer.cpp:18)
+        if (GSTACK) {
+          // a level that does not exist multiplies by 1.0f, which leaves every float as it is
+          auto level = [&](const float4& vc, const float4& vn, bool valid) {
+            const uint32_t kind = __float_as_uint(vc.w);
+            const bool is_dif = valid & (kind == VK_DIFFUSE);
+            const float wk = kind == VK_GLASS ? glass_weight : (kind == VK_FOG ? fog_albedo : diffuse_weight);
+            const float w = valid ? wk : 1.0f;
+            const float dn = dot4(dfin, V4{vn.x, vn.y, vn.z, vn.w});
+            float tr_ = is_dif ? cr * vc.x : cr, tg_ = is_dif ? cg * vc.y : cg, tb_ = is_dif ? cb * vc.z : cb;
+            tr_ = is_dif ? tr_ * dn : tr_; tg_ = is_dif ? tg_ * dn : tg_; tb_ = is_dif ? tb_ * dn : tb_;
+            cr = tr_ * w; cg = tg_ * w; cb = tb_ * w;
+          };
+          int k = job_sp - 1;
+          level(qc0, qn0, k >= 0); level(qc1, qn1, k >= 1); level(qc2, qn2, k >= 2); level(qc3, qn3, k >= 3);
+          for (k -= 4; k >= 0; k -= 4) {  // jobs of more than four vertices: four more per round
+            const size_t i0 = (size_t)k * a.vstride, i1 = (size_t)(k > 1 ? k - 1 : 0) * a.vstride;
+            const size_t i2 = (size_t)(k > 2 ? k - 2 : 0) * a.vstride, i3 = (size_t)(k > 3 ? k - 3 : 0) * a.vstride;
+            qc0 = vsc[i0]; qc1 = vsc[i1]; qc2 = vsc[i2]; qc3 = vsc[i3];
+            qn0 = vsn[i0]; qn1 = vsn[i1]; qn2 = vsn[i2]; qn3 = vsn[i3];
+            level(qc0, qn0, true); level(qc1, qn1, k >= 1); level(qc2, qn2, k >= 2); level(qc3, qn3, k >= 3);
+          }
+        } else
         for (int k = job_sp - 1; k >= 0; --k) {
           const uint32_t tag = tags[((size_t)(b * P.max_depth + k)) * BLOCK + tid];
           const bool is_glass = tag == TAGV_GLASS, is_fog = tag == TAGV_FOG;
           const bool is_dif = !(is_glass | is_fog);
           const uint32_t prim = is_dif ? tag : 0u;  // the others read record 0 and do not use it
-          const ShadeRec sv = shade_tab[prim];
+          const ShadeRec sv = (BVH ? MIPT_SC(shade) : shade_tab)[prim];
           V4 N = {sv.nx, sv.ny, sv.nz, sv.nw};
-          if (a.sc.n_spheres > 0 && (int)prim >= a.sc.n_tris) {
+          if (MIPT_SC(n_spheres) > 0 && (int)prim >= MIPT_SC(n_tris)) {
             const float* q = sph_n + ((size_t)k * BLOCK + tid) * 4;
             N = {q[0], q[1], q[2], q[3]};
           }
           const float dn = dot4(dfin, N);
-          // glass: (c * 1) * weight (pathtracer.cpp:62); fog: c * albedo; diffuse, with the direction of
-          // the last segment: (((c * colour) * dn) * 1) * weight (pathtracer.cpp:18)
           const float w = is_glass ? glass_weight : (is_fog ? fog_albedo : diffuse_weight);
           float tr_ = is_dif ? cr * sv.r : cr, tg_ = is_dif ? cg * sv.g : cg, tb_ = is_dif ? cb * sv.b : cb;
           tr_ = is_dif ? tr_ * dn : tr_; tg_ = is_dif ? tg_ * dn : tg_; tb_ = is_dif ? tb_ * dn : tb_;
@@ -1039,6 +1138,8 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
     }
   }
 
+#undef MIPT_VTOP
+#undef MIPT_SC
   if (STATS) {
     // wave-level sums, one atomic per counter per wave
 #pragma unroll

@@ -8,7 +8,17 @@
 // the paths one GPU would trace -- launches every part on its device's own stream, and sums the
 // per-device images on the first device with ONE collective: ncclReduce(sum, float32, 3 W H) over
 // RCCL (xGMI between the GPUs of a node), inside a group call since all ranks live in this thread.
-// librccl.so is loaded on first use (dlopen), so the library has no load-time dependency on it.
+// The first device renders straight into the image the reduce lands in (in-place at the root), so
+// nothing is added on the host. librccl.so is loaded on first use (dlopen), so the library has no
+// load-time dependency on it.
+//
+// The relay ("chained") variant needs no collective: the devices trace whole work items at once and
+// the image then travels from device to device by peer copies, each folding its items in -- the
+// additions happen in the order ONE device performs them, so the bits do not depend on the number of
+// devices.
+//
+// MiptMultiFrame keeps the progressive image (`pixels` + `samplesSeenSoFar`, main.cpp:50-60) on the
+// devices: adding samples is asynchronous, and presenting moves only the ARGB screen to the host.
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -23,6 +33,7 @@
 #include "../../include/mipt.h"
 
 extern "C" int mipt_internal_fail(int code, const char* msg);
+extern "C" void mipt_internal_discard_items(MiptScene* s);
 
 namespace {
 
@@ -84,18 +95,18 @@ struct Part {
   int device = 0;
   MiptScene* scene = nullptr;
   hipStream_t stream = nullptr;
-  float* d_image = nullptr;  // this device's samples of the current call
+  float* d_image = nullptr;  // this device's samples of the current call (the first device: the image the reduce lands in)
   ncclComm_t comm = nullptr;
-  hipEvent_t folded = nullptr;  // chained rendering: this device's items are in its image
+  hipEvent_t folded = nullptr;  // relay: this device's items are in the image it holds
 };
 
 }  // namespace
 
 struct MiptMulti {
   std::vector<Part> parts;
-  float* d_total = nullptr;  // on parts[0].device: the reduced image
-  float* h_total = nullptr;  // pinned staging buffer
+  float* h_total = nullptr;  // pinned staging buffer of the host-pointer calls
   size_t image_floats = 0;
+  bool shared = false;  // some device is listed more than once (rehearsal): no communicator, relay only
 };
 
 // rank r of n gets a contiguous share; the first count % n ranks one sample more
@@ -132,8 +143,6 @@ extern "C" void mipt_multi_destroy(MiptMulti* m) {
     if (p.stream) (void)hipStreamDestroy(p.stream);
     if (p.scene) mipt_scene_destroy(p.scene);
   }
-  if (!m->parts.empty()) (void)hipSetDevice(m->parts[0].device);
-  if (m->d_total) (void)hipFree(m->d_total);
   if (m->h_total) (void)hipHostFree(m->h_total);
   (void)hipGetLastError();  // a failure while tearing down is not the next call's error
   delete m;
@@ -141,34 +150,55 @@ extern "C" void mipt_multi_destroy(MiptMulti* m) {
 
 static int multi_create_impl(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres, size_t n_spheres,
                              const int* devices, int n_devices, MiptMulti* m) {
-  int rc = load_rccl();
-  if (rc != MIPT_OK) return rc;
+  if (!m->shared) {
+    const int rc = load_rccl();
+    if (rc != MIPT_OK) return rc;
+  }
   m->parts.resize((size_t)n_devices);
   for (int r = 0; r < n_devices; ++r) {
     Part& p = m->parts[(size_t)r];
     p.device = devices[r];
-    rc = mipt_scene_create(tris, n_tris, spheres, n_spheres, p.device, &p.scene);
+    const int rc = mipt_scene_create(tris, n_tris, spheres, n_spheres, p.device, &p.scene);
     if (rc != MIPT_OK) return rc;
     HIP_TRY(hipSetDevice(p.device));
     HIP_TRY(hipStreamCreate(&p.stream));
     HIP_TRY(hipEventCreateWithFlags(&p.folded, hipEventDisableTiming));
   }
+  // the relay's copies go straight over xGMI where the devices can reach each other's memory (they
+  // are staged through the host otherwise: slower, still correct)
+  for (int a = 0; a < n_devices; ++a)
+    for (int b = 0; b < n_devices; ++b) {
+      if (devices[a] == devices[b]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+        (void)hipSetDevice(devices[a]);
+        (void)hipDeviceEnablePeerAccess(devices[b], 0);  // "already enabled" is fine
+      }
+      (void)hipGetLastError();
+    }
+  if (m->shared) return MIPT_OK;
   std::vector<ncclComm_t> comms((size_t)n_devices);
   RCCL_TRY(g_rccl.CommInitAll(comms.data(), n_devices, devices));
   for (int r = 0; r < n_devices; ++r) m->parts[(size_t)r].comm = comms[(size_t)r];
   return MIPT_OK;
 }
 
-extern "C" int mipt_multi_create(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres, size_t n_spheres,
-                                 const int* devices, int n_devices, MiptMulti** out) {
+extern "C" int mipt_multi_create_opts(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres,
+                                      size_t n_spheres, const int* devices, int n_devices, uint32_t options,
+                                      MiptMulti** out) {
   if (!out) return fail(MIPT_E_INVALID, "mipt_multi_create: out is null");
   *out = nullptr;
+  if (options & ~(uint32_t)MIPT_MULTI_ALLOW_SHARED_DEVICE) return fail(MIPT_E_INVALID, "mipt_multi_create_opts: unknown option bits");
   if (!devices || n_devices < 1 || n_devices > 64) return fail(MIPT_E_INVALID, "mipt_multi_create: need 1..64 devices");
+  bool shared = false;
   for (int a = 0; a < n_devices; ++a)
     for (int b = a + 1; b < n_devices; ++b)
-      if (devices[a] == devices[b]) return fail(MIPT_E_INVALID, "mipt_multi_create: a device is listed twice");
+      if (devices[a] == devices[b]) shared = true;
+  if (shared && !(options & MIPT_MULTI_ALLOW_SHARED_DEVICE))
+    return fail(MIPT_E_INVALID, "mipt_multi_create: a device is listed twice");
   MiptMulti* m = new (std::nothrow) MiptMulti();
   if (!m) return fail(MIPT_E_NOMEM, "mipt_multi_create: host allocation failed");
+  m->shared = shared;
   int rc;
   try {
     rc = multi_create_impl(tris, n_tris, spheres, n_spheres, devices, n_devices, m);
@@ -180,6 +210,11 @@ extern "C" int mipt_multi_create(const MiptTriangle* tris, size_t n_tris, const 
   return MIPT_OK;
 }
 
+extern "C" int mipt_multi_create(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres, size_t n_spheres,
+                                 const int* devices, int n_devices, MiptMulti** out) {
+  return mipt_multi_create_opts(tris, n_tris, spheres, n_spheres, devices, n_devices, 0u, out);
+}
+
 extern "C" int mipt_multi_device_count(const MiptMulti* m) { return m ? (int)m->parts.size() : 0; }
 extern "C" MiptScene* mipt_multi_scene(MiptMulti* m, int rank) {
   return (m && rank >= 0 && (size_t)rank < m->parts.size()) ? m->parts[(size_t)rank].scene : nullptr;
@@ -187,64 +222,147 @@ extern "C" MiptScene* mipt_multi_scene(MiptMulti* m, int rank) {
 
 static int ensure_images(MiptMulti* m, size_t n) {
   if (n == m->image_floats) return MIPT_OK;
+  // no size is valid until every buffer below exists: an allocation that fails part-way must not
+  // leave the old size standing over freed or differently sized buffers
+  m->image_floats = 0;
   for (Part& p : m->parts) {
     HIP_TRY(hipSetDevice(p.device));
     HIP_TRY(hipStreamSynchronize(p.stream));
     if (p.d_image) { (void)hipFree(p.d_image); p.d_image = nullptr; }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p.d_image), n * sizeof(float)));
   }
-  HIP_TRY(hipSetDevice(m->parts[0].device));
-  if (m->d_total) { (void)hipFree(m->d_total); m->d_total = nullptr; }
   if (m->h_total) { (void)hipHostFree(m->h_total); m->h_total = nullptr; }
-  m->image_floats = 0;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_total), n * sizeof(float)));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_total), n * sizeof(float), hipHostMallocDefault));
   m->image_floats = n;
   return MIPT_OK;
 }
 
-extern "C" int mipt_multi_render_accumulate(MiptMulti* m, const MiptCamera* cam, const MiptLight* light,
-                                            const MiptParams* params, uint32_t sample_begin, uint32_t sample_count,
-                                            float* accum_rgb) {
-  if (!m || !params || !accum_rgb) return fail(MIPT_E_INVALID, "mipt_multi_render_accumulate: null argument");
-  if (params->width <= 0 || params->height <= 0 || params->width > 32768 || params->height > 32768)
-    return fail(MIPT_E_INVALID, "mipt_multi_render_accumulate: image size out of range");
-  if (sample_count == 0) return MIPT_OK;
+// After a failed step: every stream drained, every replica ready for the next render call.
+static void settle(MiptMulti* m) {
+  for (Part& p : m->parts) {
+    (void)hipSetDevice(p.device);
+    (void)hipStreamSynchronize(p.stream);
+    mipt_internal_discard_items(p.scene);
+  }
+  (void)hipGetLastError();
+}
+
+// Samples [begin, begin + count) of every pixel, split over the devices, summed into `root_image` on the
+// first device (which renders straight into it; the others into images[r]): one grouped ncclReduce,
+// in place at the root. Asynchronous.
+static int reduce_render(MiptMulti* m, const MiptCamera* cam, const MiptLight* light, const MiptParams* params,
+                         uint32_t begin, uint32_t count, float* root_image, const std::vector<float*>& images) {
   const size_t n = (size_t)params->width * params->height * 3;
-  int rc = ensure_images(m, n);
-  if (rc != MIPT_OK) return rc;
   const int world = (int)m->parts.size();
   for (int r = 0; r < world; ++r) {  // every device renders its share, asynchronously
     Part& p = m->parts[(size_t)r];
     uint32_t b = 0, c = 0;
-    mipt_multi_sample_range(sample_begin, sample_count, r, world, &b, &c);
+    mipt_multi_sample_range(begin, count, r, world, &b, &c);
     HIP_TRY(hipSetDevice(p.device));
-    HIP_TRY(hipMemsetAsync(p.d_image, 0, n * sizeof(float), p.stream));
+    float* image = r == 0 ? root_image : images[(size_t)r];
+    if (r != 0) HIP_TRY(hipMemsetAsync(image, 0, n * sizeof(float), p.stream));
     if (c) {
-      rc = mipt_render_accumulate_dev(p.scene, cam, light, params, b, c, p.d_image, p.stream);
+      const int rc = mipt_render_accumulate_dev(p.scene, cam, light, params, b, c, image, p.stream);
       if (rc != MIPT_OK) return rc;
     }
   }
-  // the one exchange step: sum of the per-device images on the first device
+  // the one exchange step: sum of the per-device images on the first device (a communicator of one
+  // rank goes through the same call)
   RCCL_TRY(g_rccl.GroupStart());
   for (int r = 0; r < world; ++r) {
     Part& p = m->parts[(size_t)r];
-    const ncclResult_t res = g_rccl.Reduce(p.d_image, r == 0 ? m->d_total : p.d_image, n, ncclFloat32, ncclSum, 0,
-                                           p.comm, p.stream);
+    float* image = r == 0 ? root_image : images[(size_t)r];
+    const ncclResult_t res = g_rccl.Reduce(image, image, n, ncclFloat32, ncclSum, 0, p.comm, p.stream);
     if (res != ncclSuccess) {
       (void)g_rccl.GroupEnd();
       return fail(MIPT_E_RCCL, "ncclReduce failed: %s", g_rccl.GetErrorString(res));
     }
   }
   RCCL_TRY(g_rccl.GroupEnd());
-  Part& root = m->parts[0];
-  HIP_TRY(hipSetDevice(root.device));
-  HIP_TRY(hipMemcpyAsync(m->h_total, m->d_total, n * sizeof(float), hipMemcpyDeviceToHost, root.stream));
-  for (int r = 0; r < world; ++r) {
-    HIP_TRY(hipSetDevice(m->parts[(size_t)r].device));
-    HIP_TRY(hipStreamSynchronize(m->parts[(size_t)r].stream));
+  return MIPT_OK;
+}
+
+// The relay: the devices order[0 .. n_order) trace the whole work items of their shares at once; the
+// image, which sits in images[order[0]], is folded there and then handed on by peer copies, each
+// device folding its items in. Returns in *last the device that holds the image afterwards.
+// Asynchronous.
+static int relay_render(MiptMulti* m, const MiptCamera* cam, const MiptLight* light, const MiptParams* params,
+                        uint32_t begin, uint32_t count, const std::vector<int>& order, const std::vector<float*>& images,
+                        int* last) {
+  const size_t n = (size_t)params->width * params->height * 3;
+  const int world = (int)order.size();
+  std::vector<uint32_t> counts((size_t)world);
+  for (int k = 0; k < world; ++k) {  // all devices trace at once
+    Part& p = m->parts[(size_t)order[(size_t)k]];
+    uint32_t b = 0, c = 0;
+    mipt_multi_item_range(begin, count, k, world, &b, &c);
+    counts[(size_t)k] = c;
+    if (!c) continue;
+    const int rc = mipt_render_items_dev(p.scene, cam, light, params, b, c, p.stream);
+    if (rc != MIPT_OK) return rc;
   }
-  for (size_t i = 0; i < n; ++i) accum_rgb[i] += m->h_total[i];  // main.cpp:137, for the whole range at once
+  int holder = order[0];
+  for (int k = 0; k < world; ++k) {  // the image's round: peer copy, fold, mark
+    if (!counts[(size_t)k]) continue;  // shares are handed out from the front: nothing further down either
+    const int r = order[(size_t)k];
+    Part& p = m->parts[(size_t)r];
+    HIP_TRY(hipSetDevice(p.device));
+    if (r != holder) {
+      Part& q = m->parts[(size_t)holder];
+      HIP_TRY(hipStreamWaitEvent(p.stream, q.folded, 0));
+      HIP_TRY(hipMemcpyPeerAsync(images[(size_t)r], p.device, images[(size_t)holder], q.device, n * sizeof(float), p.stream));
+      holder = r;
+    }
+    const int rc = mipt_fold_items_dev(p.scene, images[(size_t)r], p.stream);
+    if (rc != MIPT_OK) return rc;
+    HIP_TRY(hipEventRecord(p.folded, p.stream));
+  }
+  *last = holder;
+  return MIPT_OK;
+}
+
+static int check_call(const char* who, const MiptMulti* m, const MiptParams* params, const void* buffer) {
+  if (!m || !params || !buffer) return fail(MIPT_E_INVALID, "%s: null argument", who);
+  if (params->width <= 0 || params->height <= 0 || params->width > 32768 || params->height > 32768)
+    return fail(MIPT_E_INVALID, "%s: image size out of range", who);
+  return MIPT_OK;
+}
+
+static int sync_all(MiptMulti* m) {
+  for (Part& p : m->parts) {
+    HIP_TRY(hipSetDevice(p.device));
+    HIP_TRY(hipStreamSynchronize(p.stream));
+  }
+  return MIPT_OK;
+}
+
+extern "C" int mipt_multi_render_accumulate(MiptMulti* m, const MiptCamera* cam, const MiptLight* light,
+                                            const MiptParams* params, uint32_t sample_begin, uint32_t sample_count,
+                                            float* accum_rgb) {
+  int rc = check_call("mipt_multi_render_accumulate", m, params, accum_rgb);
+  if (rc != MIPT_OK) return rc;
+  if (m->shared)
+    return fail(MIPT_E_UNSUPPORTED, "mipt_multi_render_accumulate: RCCL takes one rank per device; a scene with a shared "
+                                    "device renders through mipt_multi_render_accumulate_chained");
+  if (sample_count == 0) return MIPT_OK;
+  const size_t n = (size_t)params->width * params->height * 3;
+  rc = ensure_images(m, n);
+  if (rc != MIPT_OK) return rc;
+  // the caller's running sums go to the first device, which adds its own samples to them (main.cpp:137)
+  // and then receives the other devices' in the reduce
+  Part& root = m->parts[0];
+  memcpy(m->h_total, accum_rgb, n * sizeof(float));
+  HIP_TRY(hipSetDevice(root.device));
+  HIP_TRY(hipMemcpyAsync(root.d_image, m->h_total, n * sizeof(float), hipMemcpyHostToDevice, root.stream));
+  std::vector<float*> images;
+  for (Part& p : m->parts) images.push_back(p.d_image);
+  rc = reduce_render(m, cam, light, params, sample_begin, sample_count, root.d_image, images);
+  if (rc != MIPT_OK) { settle(m); return rc; }
+  HIP_TRY(hipSetDevice(root.device));
+  HIP_TRY(hipMemcpyAsync(m->h_total, root.d_image, n * sizeof(float), hipMemcpyDeviceToHost, root.stream));
+  rc = sync_all(m);
+  if (rc != MIPT_OK) return rc;
+  memcpy(accum_rgb, m->h_total, n * sizeof(float));
   return MIPT_OK;
 }
 
@@ -255,48 +373,176 @@ extern "C" int mipt_multi_render_accumulate(MiptMulti* m, const MiptCamera* cam,
 extern "C" int mipt_multi_render_accumulate_chained(MiptMulti* m, const MiptCamera* cam, const MiptLight* light,
                                                     const MiptParams* params, uint32_t sample_begin,
                                                     uint32_t sample_count, float* accum_rgb) {
-  if (!m || !params || !accum_rgb) return fail(MIPT_E_INVALID, "mipt_multi_render_accumulate_chained: null argument");
-  if (params->width <= 0 || params->height <= 0 || params->width > 32768 || params->height > 32768)
-    return fail(MIPT_E_INVALID, "mipt_multi_render_accumulate_chained: image size out of range");
+  int rc = check_call("mipt_multi_render_accumulate_chained", m, params, accum_rgb);
+  if (rc != MIPT_OK) return rc;
   if (sample_count == 0) return MIPT_OK;
   const size_t n = (size_t)params->width * params->height * 3;
-  int rc = ensure_images(m, n);
+  rc = ensure_images(m, n);
   if (rc != MIPT_OK) return rc;
   const int world = (int)m->parts.size();
-  std::vector<uint32_t> counts((size_t)world);
-  for (int r = 0; r < world; ++r) {  // all devices trace at once
-    Part& p = m->parts[(size_t)r];
-    uint32_t b = 0, c = 0;
-    mipt_multi_item_range(sample_begin, sample_count, r, world, &b, &c);
-    counts[(size_t)r] = c;
-    if (!c) continue;
-    rc = mipt_render_items_dev(p.scene, cam, light, params, b, c, p.stream);
-    if (rc != MIPT_OK) return rc;
-  }
+  Part& first = m->parts[0];
   memcpy(m->h_total, accum_rgb, n * sizeof(float));
-  for (int r = 0; r < world; ++r) {  // the image's round: upload / peer copy, fold, mark
-    Part& p = m->parts[(size_t)r];
-    HIP_TRY(hipSetDevice(p.device));
-    if (r == 0) {
-      HIP_TRY(hipMemcpyAsync(p.d_image, m->h_total, n * sizeof(float), hipMemcpyHostToDevice, p.stream));
-    } else {
-      Part& q = m->parts[(size_t)r - 1];
-      HIP_TRY(hipStreamWaitEvent(p.stream, q.folded, 0));
-      HIP_TRY(hipMemcpyPeerAsync(p.d_image, p.device, q.d_image, q.device, n * sizeof(float), p.stream));
-    }
-    if (counts[(size_t)r]) {
-      rc = mipt_fold_items_dev(p.scene, p.d_image, p.stream);
-      if (rc != MIPT_OK) return rc;
-    }
-    HIP_TRY(hipEventRecord(p.folded, p.stream));
-  }
-  Part& last = m->parts[(size_t)world - 1];
+  HIP_TRY(hipSetDevice(first.device));
+  HIP_TRY(hipMemcpyAsync(first.d_image, m->h_total, n * sizeof(float), hipMemcpyHostToDevice, first.stream));
+  std::vector<int> order;
+  std::vector<float*> images;
+  for (int r = 0; r < world; ++r) { order.push_back(r); images.push_back(m->parts[(size_t)r].d_image); }
+  int holder = 0;
+  rc = relay_render(m, cam, light, params, sample_begin, sample_count, order, images, &holder);
+  if (rc != MIPT_OK) { settle(m); return rc; }
+  Part& last = m->parts[(size_t)holder];
   HIP_TRY(hipSetDevice(last.device));
   HIP_TRY(hipMemcpyAsync(m->h_total, last.d_image, n * sizeof(float), hipMemcpyDeviceToHost, last.stream));
-  for (int r = 0; r < world; ++r) {
-    HIP_TRY(hipSetDevice(m->parts[(size_t)r].device));
-    HIP_TRY(hipStreamSynchronize(m->parts[(size_t)r].stream));
-  }
+  rc = sync_all(m);
+  if (rc != MIPT_OK) return rc;
   memcpy(accum_rgb, m->h_total, n * sizeof(float));
   return MIPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// progressive frame on several devices
+
+struct MiptMultiFrame {
+  MiptMulti* multi = nullptr;
+  int width = 0, height = 0;
+  uint32_t mode = 0;
+  uint32_t samples = 0;
+  int home = 0;               // the device that holds the image (always 0 in reduce mode)
+  bool poisoned = false;      // a call failed half-way: the image is undefined until the next reset
+  std::vector<float*> images;    // one image per device: the frame's where it is `home`, staging elsewhere
+  std::vector<uint32_t*> screens;  // ARGB screen on every device that can come to hold the image
+};
+
+extern "C" void mipt_multi_frame_destroy(MiptMultiFrame* f) {
+  if (!f) return;
+  MiptMulti* m = f->multi;
+  for (size_t r = 0; r < m->parts.size(); ++r) {
+    (void)hipSetDevice(m->parts[r].device);
+    (void)hipStreamSynchronize(m->parts[r].stream);
+    if (r < f->images.size() && f->images[r]) (void)hipFree(f->images[r]);
+    if (r < f->screens.size() && f->screens[r]) (void)hipFree(f->screens[r]);
+  }
+  (void)hipGetLastError();
+  delete f;
+}
+
+static int multi_frame_create_impl(MiptMultiFrame* f) {
+  MiptMulti* m = f->multi;
+  const size_t n = (size_t)f->width * f->height;
+  f->images.assign(m->parts.size(), nullptr);
+  f->screens.assign(m->parts.size(), nullptr);
+  for (size_t r = 0; r < m->parts.size(); ++r) {
+    HIP_TRY(hipSetDevice(m->parts[r].device));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->images[r]), n * 12));
+    // the sum-reduce always lands on the first device; the relay leaves the image where its round ended
+    if (r == 0 || f->mode == MIPT_MULTI_FRAME_EXACT) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->screens[r]), n * 4));
+  }
+  HIP_TRY(hipSetDevice(m->parts[0].device));
+  HIP_TRY(hipMemsetAsync(f->images[0], 0, n * 12, m->parts[0].stream));
+  return MIPT_OK;
+}
+
+extern "C" int mipt_multi_frame_create(MiptMulti* m, int width, int height, uint32_t mode, MiptMultiFrame** out) {
+  if (!out) return fail(MIPT_E_INVALID, "mipt_multi_frame_create: out is null");
+  *out = nullptr;
+  if (!m) return fail(MIPT_E_INVALID, "mipt_multi_frame_create: multi is null");
+  if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
+    return fail(MIPT_E_INVALID, "mipt_multi_frame_create: image size out of range");
+  if (mode != MIPT_MULTI_FRAME_REDUCE && mode != MIPT_MULTI_FRAME_EXACT)
+    return fail(MIPT_E_INVALID, "mipt_multi_frame_create: unknown mode");
+  if (mode == MIPT_MULTI_FRAME_REDUCE && m->shared)
+    return fail(MIPT_E_UNSUPPORTED, "mipt_multi_frame_create: RCCL takes one rank per device; use MIPT_MULTI_FRAME_EXACT "
+                                    "on a scene with a shared device");
+  MiptMultiFrame* f = new (std::nothrow) MiptMultiFrame();
+  if (!f) return fail(MIPT_E_NOMEM, "mipt_multi_frame_create: host allocation failed");
+  f->multi = m; f->width = width; f->height = height; f->mode = mode;
+  int rc;
+  try {
+    rc = multi_frame_create_impl(f);
+  } catch (const std::bad_alloc&) {
+    rc = fail(MIPT_E_NOMEM, "mipt_multi_frame_create: host allocation failed");
+  }
+  if (rc != MIPT_OK) { mipt_multi_frame_destroy(f); return rc; }
+  *out = f;
+  return MIPT_OK;
+}
+
+extern "C" int mipt_multi_frame_reset(MiptMultiFrame* f) {
+  if (!f) return fail(MIPT_E_INVALID, "mipt_multi_frame_reset: frame is null");
+  Part& p = f->multi->parts[(size_t)f->home];
+  HIP_TRY(hipSetDevice(p.device));
+  // the last operation on the image ran on this device's stream
+  HIP_TRY(hipMemsetAsync(f->images[(size_t)f->home], 0, (size_t)f->width * f->height * 12, p.stream));
+  f->samples = 0;
+  f->poisoned = false;
+  return MIPT_OK;
+}
+
+extern "C" int mipt_multi_frame_add_samples(MiptMultiFrame* f, const MiptCamera* cam, const MiptLight* light,
+                                            const MiptParams* params, uint32_t n_samples) {
+  if (!f || !params) return fail(MIPT_E_INVALID, "mipt_multi_frame_add_samples: null argument");
+  if (f->poisoned) return fail(MIPT_E_INVALID, "mipt_multi_frame_add_samples: an earlier call failed; reset the frame first");
+  if (n_samples == 0) return MIPT_OK;
+  if ((uint64_t)f->samples + n_samples > 0x7FFFFFFFull)
+    return fail(MIPT_E_INVALID, "mipt_multi_frame_add_samples: sample count exceeds int range");
+  MiptMulti* m = f->multi;
+  MiptParams p = *params;
+  p.width = f->width; p.height = f->height;
+  const int world = (int)m->parts.size();
+  int rc;
+  try {
+    if (f->mode == MIPT_MULTI_FRAME_REDUCE) {
+      rc = reduce_render(m, cam, light, &p, f->samples, n_samples, f->images[0], f->images);
+    } else {
+      // the round starts where the image is and ends where it will be found next time
+      std::vector<int> order;
+      for (int k = 0; k < world; ++k) order.push_back((f->home + k) % world);
+      int holder = f->home;
+      rc = relay_render(m, cam, light, &p, f->samples, n_samples, order, f->images, &holder);
+      if (rc == MIPT_OK) f->home = holder;
+    }
+  } catch (const std::bad_alloc&) {
+    rc = fail(MIPT_E_NOMEM, "mipt_multi_frame_add_samples: host allocation failed");
+  }
+  if (rc != MIPT_OK) { settle(m); f->poisoned = true; return rc; }
+  f->samples += n_samples;
+  return MIPT_OK;
+}
+
+extern "C" int mipt_multi_frame_present(MiptMultiFrame* f, uint32_t* screen_buffer) {
+  if (!f || !screen_buffer) return fail(MIPT_E_INVALID, "mipt_multi_frame_present: null argument");
+  if (f->poisoned) return fail(MIPT_E_INVALID, "mipt_multi_frame_present: an earlier call failed; reset the frame first");
+  Part& p = f->multi->parts[(size_t)f->home];
+  uint32_t* d_screen = f->screens[(size_t)f->home];
+  const int rc = mipt_resolve_argb_dev(p.scene, f->images[(size_t)f->home], f->width, f->height, f->samples, d_screen, p.stream);
+  if (rc != MIPT_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(screen_buffer, d_screen, (size_t)f->width * f->height * 4, hipMemcpyDeviceToHost, p.stream));
+  HIP_TRY(hipStreamSynchronize(p.stream));
+  return MIPT_OK;
+}
+
+extern "C" int mipt_multi_frame_read_pixels(MiptMultiFrame* f, float* accum_rgb) {
+  if (!f || !accum_rgb) return fail(MIPT_E_INVALID, "mipt_multi_frame_read_pixels: null argument");
+  Part& p = f->multi->parts[(size_t)f->home];
+  HIP_TRY(hipSetDevice(p.device));
+  HIP_TRY(hipMemcpyAsync(accum_rgb, f->images[(size_t)f->home], (size_t)f->width * f->height * 12, hipMemcpyDeviceToHost, p.stream));
+  HIP_TRY(hipStreamSynchronize(p.stream));
+  return MIPT_OK;
+}
+
+extern "C" int mipt_multi_frame_samples(const MiptMultiFrame* f) { return f ? (int)f->samples : 0; }
+
+extern "C" int mipt_multi_frame_device(const MiptMultiFrame* f) { return f ? f->home : -1; }
+
+extern "C" int mipt_multi_frame_poll(MiptMultiFrame* f) {
+  if (!f) return fail(MIPT_E_INVALID, "mipt_multi_frame_poll: frame is null");
+  for (Part& p : f->multi->parts) {
+    HIP_TRY(hipSetDevice(p.device));
+    const hipError_t e = hipStreamQuery(p.stream);
+    if (e == hipSuccess) continue;
+    (void)hipGetLastError();
+    if (e == hipErrorNotReady) return 0;
+    return fail(MIPT_E_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+  }
+  return 1;
 }

@@ -3,9 +3,11 @@
 // `closestIntersection` for single rays and `Draw` into a `screen` buffer. The vector types below
 // carry the member names the reference's glm types have (glm itself is not needed here).
 //
-//   host_demo <scene 0..3> <size> <frames> <samples_per_frame> [multi|multi-reduce]
+//   host_demo <scene 0..3> <size> <frames> <samples_per_frame> [multi|multi-reduce|multi-frame]
 // (multi: Draw goes through mipt_host::MultiGpuScene on device 0 -- the several-GPU path with one rank,
-//  image handed from device to device; multi-reduce: the RCCL sum-reduce of the per-device images)
+//  image handed from device to device; multi-reduce: the RCCL sum-reduce of the per-device images;
+//  multi-frame: mipt_host::MultiFrame over two scene replicas sharing device 0 -- the image stays on
+//  the device, only the screen comes back, `pixels` is read once at the end)
 // prints one line of key=value results that tests/test_gpu_host_cpp.py compares with the
 // Python host's results for the same inputs.
 #include <cstdio>
@@ -41,6 +43,7 @@ int main(int argc, char** argv) {
   const int spf = argc > 4 ? atoi(argv[4]) : 4;
   const bool reduce = argc > 5 && strcmp(argv[5], "multi-reduce") == 0;
   const bool multi = reduce || (argc > 5 && strcmp(argv[5], "multi") == 0);
+  const bool multi_frame = argc > 5 && strcmp(argv[5], "multi-frame") == 0;
   try {
     MiptTriangle raw[30];
     const int n = mipt_load_test_model(which, raw, 30);
@@ -88,7 +91,17 @@ int main(int argc, char** argv) {
     vec3** pixels = new vec3*[size];
     for (int x = 0; x < size; ++x) pixels[x] = new vec3[size]();
     int samplesSeenSoFar = 0;
-    if (multi) {
+    if (multi_frame) {
+      mipt_host::MultiGpuScene all(triangles, spheres, std::vector<int>{0, 0}, true);
+      mipt_host::MultiFrame frame(all, size, size);
+      for (int f = 0; f < frames; ++f) {
+        frame.add_samples(cam, light, spf);
+        frame.present(&scr);
+      }
+      while (!frame.done()) {}
+      frame.read_pixels(pixels);
+      samplesSeenSoFar = frame.samplesSeenSoFar();
+    } else if (multi) {
       mipt_host::MultiGpuScene all(triangles, spheres, std::vector<int>{0});
       all.sum_reduce = reduce;
       for (int f = 0; f < frames; ++f) mipt_host::Draw(all, &scr, cam, light, pixels, samplesSeenSoFar, spf);

@@ -181,14 +181,16 @@ inline void Draw(GpuScene& gpu, ScreenT* screen, const CameraT& cam, const Light
 class MultiGpuScene {
  public:
   template <class TriangleT, class SphereT>
+  // allow_shared_device: a device may be listed more than once (rehearsal on a one-GPU machine; relay only)
   MultiGpuScene(const std::vector<TriangleT>& triangles, const std::vector<SphereT>& spheres,
-                const std::vector<int>& devices) {
+                const std::vector<int>& devices, bool allow_shared_device = false) {
     std::vector<MiptTriangle> t;
     std::vector<MiptSphere> s;
     t.reserve(triangles.size());
     for (const auto& x : triangles) t.push_back(to_mipt(x));
     for (const auto& x : spheres) s.push_back(to_mipt_sphere(x));
-    check(mipt_multi_create(t.data(), t.size(), s.data(), s.size(), devices.data(), (int)devices.size(), &h_));
+    check(mipt_multi_create_opts(t.data(), t.size(), s.data(), s.size(), devices.data(), (int)devices.size(),
+                                 allow_shared_device ? (uint32_t)MIPT_MULTI_ALLOW_SHARED_DEVICE : 0u, &h_));
   }
   ~MultiGpuScene() { mipt_multi_destroy(h_); }
   MultiGpuScene(const MultiGpuScene&) = delete;
@@ -265,6 +267,51 @@ class Frame {
  private:
   GpuScene& gpu_;
   MiptFrame* f_ = nullptr;
+};
+
+// The same loop on all the GPUs of a MultiGpuScene: the image never leaves the devices, adding samples
+// returns as soon as the work is queued, present() brings back the ARGB screen alone.
+//     mipt_host::MultiFrame frame(*all_gpus, SCREEN_WIDTH, SCREEN_HEIGHT);      // exact = true: the one-GPU bits
+//     while (NoQuitMessageSDL()) { ...; frame.add_samples(cam, light, 64); frame.present(screen); ... }
+class MultiFrame {
+ public:
+  MultiFrame(MultiGpuScene& gpu, int width, int height, bool exact = true) : gpu_(gpu) {
+    check(mipt_multi_frame_create(gpu.handle(), width, height, exact ? MIPT_MULTI_FRAME_EXACT : MIPT_MULTI_FRAME_REDUCE, &f_));
+    if (!gpu.params_set) { mipt_params_default(&gpu.params, width, height); gpu.params_set = true; }
+    width_ = width; height_ = height;
+  }
+  ~MultiFrame() { mipt_multi_frame_destroy(f_); }
+  MultiFrame(const MultiFrame&) = delete;
+  MultiFrame& operator=(const MultiFrame&) = delete;
+  void reset() { check(mipt_multi_frame_reset(f_)); }
+  template <class CameraT, class LightT>
+  void add_samples(const CameraT& cam, const LightT& light, int n) {
+    const MiptCamera c = to_mipt_camera(cam);
+    const MiptLight l = to_mipt_light(light);
+    check(mipt_multi_frame_add_samples(f_, &c, &l, &gpu_.params, (uint32_t)n));
+  }
+  template <class ScreenT> void present(ScreenT* screen) { check(mipt_multi_frame_present(f_, screen->buffer)); }
+  // the accumulated sums into the reference's column-wise `pixels` (main.cpp:55-57), e.g. before a save
+  template <class Vec3T> void read_pixels(Vec3T** pixels) {
+    std::vector<float> accum((size_t)width_ * height_ * 3);
+    check(mipt_multi_frame_read_pixels(f_, accum.data()));
+    for (int x = 0; x < width_; ++x)
+      for (int y = 0; y < height_; ++y) {
+        const float* a = &accum[((size_t)x * height_ + y) * 3];
+        pixels[x][y].x = a[0]; pixels[x][y].y = a[1]; pixels[x][y].z = a[2];
+      }
+  }
+  int samplesSeenSoFar() const { return mipt_multi_frame_samples(f_); }
+  bool done() {
+    const int rc = mipt_multi_frame_poll(f_);
+    if (rc < 0) check(rc);
+    return rc == 1;
+  }
+
+ private:
+  MultiGpuScene& gpu_;
+  MiptMultiFrame* f_ = nullptr;
+  int width_ = 0, height_ = 0;
 };
 
 // SDL_SaveImage (SDLauxiliary.h:25-54) for the reference's `screen` struct (buffer, width, height)

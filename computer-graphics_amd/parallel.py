@@ -20,11 +20,12 @@ def rank_sample_range(sample_begin, sample_count, rank, world):
     return begin, base + (1 if rank < extra else 0)
 
 
-def reduce_image(rank_image, total, rank, world, group=None, via_host=False):
+def reduce_image(rank_image, total, rank, world, group=None, via_host=False, always=False):
     """Sum the per-rank images into rank 0's running image `total` (None on other ranks).
     via_host: the backend cannot reduce device tensors (gloo with images in HBM): the image makes
-    the round trip through host memory."""
-    if world > 1:
+    the round trip through host memory. always: call the collective even in a world of one rank
+    (a rehearsal of the backend on a one-GPU machine)."""
+    if world > 1 or always:
         import torch.distributed as dist
         if via_host and rank_image.is_cuda:
             staged = rank_image.cpu()
@@ -38,7 +39,7 @@ def reduce_image(rank_image, total, rank, world, group=None, via_host=False):
 
 
 def render_distributed(render_fn, sample_begin, sample_count, rank, world, rank_image, total, group=None,
-                       via_host=False):
+                       via_host=False, always=False):
     """render_fn(begin, count, image) must ADD samples [begin, begin+count) of every pixel into
     `image` (Scene.render_accumulate_dev, or any renderer with the same contract). After the
     call rank 0's `total` has gained the whole range [sample_begin, sample_begin+sample_count)."""
@@ -46,7 +47,7 @@ def render_distributed(render_fn, sample_begin, sample_count, rank, world, rank_
     rank_image.zero_()
     if count:
         render_fn(begin, count, rank_image)
-    reduce_image(rank_image, total, rank, world, group, via_host)
+    reduce_image(rank_image, total, rank, world, group, via_host, always)
 
 
 ITEM_SAMPLES = 16  # samples per work item of the path kernel (one lane adds them in sample order)

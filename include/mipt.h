@@ -316,7 +316,11 @@ int mipt_fold_items_dev(MiptScene* scene, float* d_accum_rgb, void* stream);
  *   ranges compose bit for bit (see mipt_render_accumulate).
  *   The array is shared by every scene and stream on a GPU (each GPU has its own copy, resident
  *   until the process ends): two such calls that overlap on one GPU race; issue them on one stream
- *   or order them yourself. mipt_get_stats' kernel_ms is not updated by this call. */
+ *   or order them yourself. The same holds for such a call and ANY other render call of the same
+ *   tree scene (a scene of MIPT_BVH_MIN_TRIS triangles or more keeps its paths' vertex stacks in
+ *   device memory it allocated at creation). mipt_get_stats is not updated by this call, and
+ *   MIPT_FLAG_STATS is refused (the counters are scene scratch ordered by events this call does not
+ *   use). */
 #define MIPT_NOALLOC_MAX_BYTES (32u << 20)
 int mipt_render_accumulate_noalloc_dev(MiptScene* scene, const MiptCamera* cam, const MiptLight* light,
                                        const MiptParams* params, uint32_t sample_begin,
@@ -358,13 +362,25 @@ int mipt_frame_poll(MiptFrame* frame);
  * contiguous parts, one per device (mipt_multi_sample_range; a path's random numbers depend on the
  * global sample index only, so the parts are exactly the paths one GPU would trace), each device
  * renders its part on its own stream, and ONE ncclReduce(sum, float32, 3 W H) over RCCL adds the
- * per-device images on the first device. The image equals the single-GPU image up to the order of
- * the float additions. librccl.so is loaded on first use; MIPT_E_RCCL if that or a collective fails. */
+ * per-device images on the first device -- which has rendered its own part straight onto the caller's
+ * running sums, so the reduce (in place at the root) leaves the new total and the host adds nothing.
+ * The image equals the single-GPU image up to the order of the float additions. librccl.so is loaded
+ * on first use; MIPT_E_RCCL if that or a collective fails. A call that fails half-way drains every
+ * device and leaves the replicas ready for the next call. */
 typedef struct MiptMulti MiptMulti;
 int mipt_multi_create(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres, size_t n_spheres,
                       const int* devices, int n_devices, MiptMulti** out);
 void mipt_multi_destroy(MiptMulti* multi);
 int mipt_multi_device_count(const MiptMulti* multi);
+/* mipt_multi_create with options. MIPT_MULTI_ALLOW_SHARED_DEVICE: a device may be listed more than once,
+ * each entry with a scene replica and a stream of its own -- for rehearsing the several-device code
+ * (sample split in work items, event chain, peer copies) on a machine with one GPU. RCCL takes one
+ * rank per device, so such a scene has no communicator: the relay calls
+ * (mipt_multi_render_accumulate_chained, MIPT_MULTI_FRAME_EXACT frames) work, the sum-reduce ones
+ * return MIPT_E_UNSUPPORTED. No counterpart in the reference. */
+enum { MIPT_MULTI_ALLOW_SHARED_DEVICE = 1u };
+int mipt_multi_create_opts(const MiptTriangle* tris, size_t n_tris, const MiptSphere* spheres, size_t n_spheres,
+                           const int* devices, int n_devices, uint32_t options, MiptMulti** out);
 /* the replica on the rank-th listed device (owned by `multi`), e.g. for mipt_resolve_argb; NULL if out of range */
 MiptScene* mipt_multi_scene(MiptMulti* multi, int rank);
 int mipt_multi_render_accumulate(MiptMulti* multi, const MiptCamera* cam, const MiptLight* light,
@@ -384,6 +400,39 @@ int mipt_multi_render_accumulate_chained(MiptMulti* multi, const MiptCamera* cam
                                          float* accum_rgb);
 void mipt_multi_item_range(uint32_t begin, uint32_t count, int rank, int n, uint32_t* part_begin,
                            uint32_t* part_count);
+
+/* mipt_frame_* on several GPUs: `vec3** pixels` + `samplesSeenSoFar` (main.cpp:50-60) resident on the
+ * devices of a MiptMulti, so that a frame of the interactive loop (main.cpp:96-101) launches work on
+ * every GPU and moves only the ARGB screen to the host -- no image crosses PCIe, nothing is added on
+ * the host.
+ *   mode MIPT_MULTI_FRAME_REDUCE  every add_samples splits its samples over the devices
+ *                                 (mipt_multi_sample_range); the first device renders straight into
+ *                                 the frame's image and ONE ncclReduce(sum) brings the others' in.
+ *   mode MIPT_MULTI_FRAME_EXACT   the relay of mipt_multi_render_accumulate_chained: whole work items
+ *                                 per device, the image handed on by peer copies; it stays on the
+ *                                 device where its round ended and the next round starts there. The
+ *                                 image is the ONE-GPU frame's (mipt_frame_*), bit for bit, for
+ *                                 additions of a multiple of 16 samples.
+ *   mipt_multi_frame_add_samples  asynchronous: returns once the work is queued on the devices' streams
+ *   mipt_multi_frame_present      Draw's tonemap loop (main.cpp:141-145) on the device holding the
+ *                                 image; waits for the samples added so far
+ *   mipt_multi_frame_reset        reset_evolutionModel (utils.cpp:24-32)
+ *   mipt_multi_frame_poll         1 when every device has finished what was queued, 0 while busy
+ *   mipt_multi_frame_device       index (into the multi's device list) of the device holding the image
+ * A call that fails half-way leaves the image undefined: the frame refuses further samples until it
+ * is reset. Destroy a frame before its MiptMulti. One host thread per MiptMulti, as for scenes. */
+typedef struct MiptMultiFrame MiptMultiFrame;
+enum { MIPT_MULTI_FRAME_REDUCE = 0u, MIPT_MULTI_FRAME_EXACT = 1u };
+int mipt_multi_frame_create(MiptMulti* multi, int width, int height, uint32_t mode, MiptMultiFrame** out);
+void mipt_multi_frame_destroy(MiptMultiFrame* frame);
+int mipt_multi_frame_reset(MiptMultiFrame* frame);
+int mipt_multi_frame_add_samples(MiptMultiFrame* frame, const MiptCamera* cam, const MiptLight* light,
+                                 const MiptParams* params, uint32_t n_samples);
+int mipt_multi_frame_present(MiptMultiFrame* frame, uint32_t* screen_buffer);
+int mipt_multi_frame_read_pixels(MiptMultiFrame* frame, float* accum_rgb);
+int mipt_multi_frame_samples(const MiptMultiFrame* frame);
+int mipt_multi_frame_device(const MiptMultiFrame* frame);
+int mipt_multi_frame_poll(MiptMultiFrame* frame);
 
 /* Counters of the most recent render / trace call made with MIPT_FLAG_STATS, and
  * the device time of its path kernel (measured with HIP events on the launch

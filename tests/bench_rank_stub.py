@@ -39,6 +39,8 @@ def main():
     total = torch.zeros_like(buf) if rank == 0 else None
 
     def step(k):
+        if sys.argv[5:] == ["die-mid-run-on-rank-5"] and rank == 5 and k == 1:
+            os._exit(9)      # between two collectives: the other ranks are left waiting in the next reduce
         parallel.render_distributed(render, k * global_spp, global_spp, rank, world, buf, total)
 
     def max_over_ranks(dt):

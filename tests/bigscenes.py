@@ -130,3 +130,42 @@ def config5(dtype, n=1000000, seed=42):
     e2 = rng.uniform(-0.01, 0.01, (n, 3))
     color = rng.uniform(0.1, 1.0, (n, 3)).astype(np.float32)
     return _finish(dtype, c, c + e1, c + e2, color, np.zeros(n, dtype=np.uint32))
+
+
+def config4_vertices(nu=320, nv=160, seed=4):
+    """The displaced torus of config4 as an indexed mesh: (nu * nv vertices, 2 nu nv faces of vertex indices)."""
+    rng = np.random.default_rng(seed)
+    ph = rng.uniform(0, 2 * np.pi, 4)
+    u = np.linspace(0, 2 * np.pi, nu, endpoint=False)
+    v = np.linspace(0, 2 * np.pi, nv, endpoint=False)
+    U, V = np.meshgrid(u, v, indexing="ij")
+    rr = 0.16 * (1 + 0.18 * np.sin(5 * U + ph[0]) * np.cos(3 * V + ph[1]) + 0.05 * np.sin(17 * U + 11 * V + ph[2]))
+    R = 0.38
+    P = np.stack([(R + rr * np.cos(V)) * np.cos(U), rr * np.sin(V) + 0.08 * np.sin(2 * U + ph[3]) - 0.2,
+                  (R + rr * np.cos(V)) * np.sin(U)], axis=-1).reshape(-1, 3)
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    a = (i * nv + j).ravel()
+    b = (((i + 1) % nu) * nv + j).ravel()
+    c = (((i + 1) % nu) * nv + (j + 1) % nv).ravel()
+    d = (i * nv + (j + 1) % nv).ravel()
+    faces = np.concatenate([np.stack([a, b, c], axis=1), np.stack([a, c, d], axis=1)])
+    return P, faces
+
+
+def write_obj(path, vertices, faces, with_normals):
+    """A Wavefront OBJ file of an indexed triangle mesh: `v` records, optionally one `vn` per vertex
+    (the normalised sum of the adjacent face normals) with `f a//a b//b c//c` faces, else `f a b c`."""
+    lines = ["# procedural mesh", "o mesh"]
+    lines += ["v %.9g %.9g %.9g" % tuple(p) for p in vertices]
+    if with_normals:
+        fn = np.cross(vertices[faces[:, 1]] - vertices[faces[:, 0]], vertices[faces[:, 2]] - vertices[faces[:, 0]])
+        vn = np.zeros_like(vertices)
+        for k in range(3):
+            np.add.at(vn, faces[:, k], fn)
+        vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-30)
+        lines += ["vn %.9g %.9g %.9g" % tuple(n) for n in vn]
+        lines += ["f %d//%d %d//%d %d//%d" % (a, a, b, b, c, c) for a, b, c in faces + 1]
+    else:
+        lines += ["f %d %d %d" % (a, b, c) for a, b, c in faces + 1]
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")

@@ -412,6 +412,122 @@ def test_shipped_path_kernel_on_config4(api, O, dtype, pkg):
     tree.close(); lin.close()
 
 
+@pytest.mark.parametrize("with_normals", [False, True])
+def test_config3_mesh_through_the_obj_loader(api, O, dtype, pkg, tmp_path, with_normals):
+    # BASELINE configs[3] as it is worded -- "Cornell box + LOADED OBJ mesh (~100 k tris)": the 102 400-
+    # triangle mesh written as a Wavefront file (with and without vn records), read back by mipt_load_obj
+    # (LoadObject, parser.cpp:8-46), placed by mipt_normalise_triangles the way main.cpp:78-89 places
+    # the wolf (vertex w = 1 / L afterwards, unnormalised face normals without vn), appended to
+    # LoadTestModelNone's room; the LBVH over it against the device's linear scan (2^16 rays of each kind)
+    # and the CPU oracle (1000 rays), and a frame of whole paths against the linear scan
+    import torch
+    V, F = bigscenes.config4_vertices()
+    path = str(tmp_path / "mesh.obj")
+    bigscenes.write_obj(path, V, F, with_normals)
+    raw = api.load_obj(path)
+    assert len(raw) == len(F) == 102400
+    if not with_normals:    # OBJ_Loader.h:811-822: the cross product of the face's edges, unnormalised
+        assert np.abs(np.linalg.norm(raw["normal"][:, :3], axis=1) - 1).max() > 0.5
+    mesh = api.normalise_triangles(raw, 1.2, (0.05, 0.1, -0.1), (0.3, -0.4, 0.1), (-1, 1, 1), pkg.abi.MAT_GLASS)
+    assert 0 < mesh["v0"][0][3] != 1.0 and np.abs(mesh["v0"][:, :3]).max() < 1.0
+    tris = np.concatenate([api.load_test_model(3), mesh])
+    tree = api.Scene(tris)
+    lin = api.Scene(tris, linear_scan=True)
+    assert tree.bvh_info()[0] and not lin.bvh_info()[0]
+    n = 1 << 16
+    fams = {"primary": raygen.primary_rays(n), "interior": raygen.interior_rays(n, seed=22),
+            "surface": raygen.surface_rays(tris, n, seed=23)}
+    for kind, (o, d) in fams.items():
+        do, dd = _dev(o), _dev(d)
+        a = _batch(tree, do, dd)
+        b = _batch(lin, do, dd)
+        assert _same_hits(a, b), (kind, int((a[0] != b[0]).sum()))
+        assert (b[0] >= 10).float().mean() > 0.02, kind      # the mesh itself is hit
+        m = 1000
+        idx, t, pos = tree.closest_hit(o[:m], d[:m])
+        oidx, ot, opos = O.closest_hit(tris, None, o[:m], d[:m])
+        assert np.array_equal(idx, oidx), kind
+        hit = oidx >= 0
+        assert np.array_equal(bits(t[hit]), bits(ot[hit])) and np.array_equal(bits(pos[hit]), bits(opos[hit]))
+    so, sd, sr = raygen.shadow_rays(tris, n, seed=24)
+    a = _batch(tree, _dev(so), _dev(sd), _dev(sr))
+    b = _batch(lin, _dev(so), _dev(sd), _dev(sr))
+    assert torch.equal(a[3], b[3]) and 0 < int(b[3].sum()) < n
+    W = H = 256
+    cam, light = api.default_camera(W), api.default_light(True)
+    p = api.default_params(W, H, seed=8, rng_mode=pkg.abi.RNG_COUNTER, fog_sigma_t=0.1, flags=pkg.abi.FLAG_STATS)
+    x = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    y = torch.zeros_like(x)
+    tree.render_accumulate_dev(cam, light, p, 0, 16, x)
+    torch.cuda.synchronize()
+    st = tree.stats()
+    lin.render_accumulate_dev(cam, light, p, 0, 16, y)
+    torch.cuda.synchronize()
+    sl = lin.stats()
+    assert st.glass_bounces == sl.glass_bounces > 10000 and st.closest_rays == sl.closest_rays
+    assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    tree.close(); lin.close()
+
+
+def test_whole_paths_on_config5_match_the_oracle(api, O, dtype, pkg):
+    # BASELINE configs[4]'s scene (10^6 random diffuse triangles): a small frame of whole paths through
+    # the LBVH against the CPU oracle's linear scan, in the GPU's association -- every channel sum bit-equal
+    tris = bigscenes.config5(dtype)
+    W = H = 24
+    cam, light = api.default_camera(W), api.default_light(True)
+    p = api.default_params(W, H, seed=4, rng_mode=pkg.abi.RNG_MINSTD_PATH)
+    sc = api.Scene(tris)
+    got = sc.render_accumulate(cam, light, p, 0, 16)
+    want = oracle_image(O, tris, None, cam, light, p, 16)
+    assert want.sum() > 0 and np.array_equal(bits(got), bits(want)), int((bits(got) != bits(want)).sum())
+    sc.close()
+
+
+def test_linear_scan_of_a_big_diffuse_mesh_keeps_its_vertex_indices(api, O, dtype, pkg):
+    # mipt_scene_create_opts(MIPT_SCENE_LINEAR_SCAN) on 102 410 triangles, the mesh DIFFUSE: the path's
+    # vertex stack holds hit indices beyond 65 535 (a 16-bit tag would read another triangle's normal and
+    # colour, or mistake index 65 533 / 65 534 for a fog / glass mark). Image and counters = the tree's,
+    # and listed paths = the oracle's, bit for bit.
+    import torch
+    import bigscenes
+    tris = bigscenes.config4(O, dtype, material=0)
+    tris["color"][10:] = np.random.default_rng(1).uniform(0.2, 0.9, (len(tris) - 10, 3)).astype(np.float32)
+    W, H = 96, 96
+    cam, light = api.default_camera(W), api.default_light(True)
+    tree = api.Scene(tris)
+    lin = api.Scene(tris, linear_scan=True)
+    for rng_mode, fog in ((pkg.abi.RNG_COUNTER, 0.0), (pkg.abi.RNG_MINSTD_PATH, 0.15)):
+        p = api.default_params(W, H, seed=6, rng_mode=rng_mode, fog_sigma_t=fog, flags=pkg.abi.FLAG_STATS)
+        a = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+        b = torch.zeros_like(a)
+        tree.render_accumulate_dev(cam, light, p, 0, 24, a)
+        torch.cuda.synchronize()
+        st = tree.stats()
+        lin.render_accumulate_dev(cam, light, p, 0, 24, b)
+        torch.cuda.synchronize()
+        sl = lin.stats()
+        for k in ("paths", "closest_rays", "shadow_rays", "diffuse_bounces", "fog_events"):
+            assert getattr(st, k) == getattr(sl, k), (k, getattr(st, k), getattr(sl, k))
+        assert st.diffuse_bounces > 100000 and a.sum().item() > 0
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (rng_mode, fog)
+        p.flags = 0     # the shipped kernel of the linear scan
+        c = torch.zeros_like(a)
+        lin.render_accumulate_dev(cam, light, p, 0, 24, c)
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.int32), c.view(torch.int32)), (rng_mode, fog)
+    # paths through the mesh's middle (the torus is in the lower half of the image), against the oracle
+    p = api.default_params(W, H, seed=6, rng_mode=pkg.abi.RNG_MINSTD_PATH)
+    rng = np.random.default_rng(2)
+    n = 300
+    px = rng.integers(W // 4, 3 * W // 4, n).astype(np.int32)
+    py = rng.integers(H // 2, 3 * H // 4, n).astype(np.int32)
+    smp = rng.integers(0, 1000, n).astype(np.uint32)
+    rgb, counts = lin.trace_paths(cam, light, p, px, py, smp)
+    orgb, ocounts = O.trace_paths(tris, None, cam, light, p, px, py, smp)
+    assert np.array_equal(counts, ocounts) and np.array_equal(bits(rgb), bits(orgb)) and (rgb.sum(axis=1) > 0).sum() > 20
+    tree.close(); lin.close()
+
+
 @pytest.mark.parametrize("name", ["mesh9k", "glasswolf", "soup300"])
 def test_shipped_path_kernels_equal_counting_kernels(api, O, dtype, pkg, name):
     # flags = 0 (the kernels that ship: early end at unlit terminal vertices, other register and LDS

@@ -626,6 +626,35 @@ def test_box_units_equal_literal_scan(api, O, pkg, seed, sizes):
     check_closest(api, O, tris, None, o, d)
 
 
+def test_eight_two_face_boxes_in_one_chunk(api, O, pkg):
+    # eight L-shaped quad pairs fill a chunk of 32 triangles: seven become box units, the eighth stays two
+    # pair units (the chunk's count field holds 7); the shipped scan = the literal scan on generated rays,
+    # and closest hits = the oracle's
+    from test_host_library import l_shapes
+    for n in (8, 16):
+        tris = l_shapes(pkg.abi, n)
+        sc = api.Scene(tris)
+        assert sc.box_units() == 7 * (n // 8) and sc.pair_units() == 2 * n
+        _, _, bad_closest, bad_any = sc.selfcheck(1 << 24, seed=n)
+        assert bad_closest == 0 and bad_any == 0
+        rng = np.random.default_rng(n)
+        m = 4096
+        o = np.ones((m, 4), dtype=np.float32)
+        o[:, :3] = rng.uniform(-1, 1, (m, 3))
+        k = rng.integers(0, len(tris), m)       # aimed at a point of some triangle (it may hit another first)
+        u = rng.uniform(0, 1, m)
+        v = rng.uniform(0, 1, m) * (1 - u)
+        target = tris["v0"][k, :3] + u[:, None] * (tris["v1"][k, :3] - tris["v0"][k, :3]) + v[:, None] * (tris["v2"][k, :3] - tris["v0"][k, :3])
+        d = np.ones((m, 4), dtype=np.float32)
+        d[:, :3] = target - o[:, :3] + rng.normal(scale=0.02, size=(m, 3))
+        idx, t, pos = sc.closest_hit(o, d)
+        oidx, ot, opos = O.closest_hit(tris, None, o, d)
+        hit = oidx >= 0
+        assert hit.sum() > 1000 and np.array_equal(idx, oidx)
+        assert np.array_equal(bits(t[hit]), bits(ot[hit])) and np.array_equal(bits(pos[hit]), bits(opos[hit]))
+        sc.close()
+
+
 @pytest.mark.parametrize("seed", [4, 5])
 def test_axis_plane_pairs_equal_literal_scan(api, O, pkg, seed):
     # quads in planes normal to a coordinate axis take the filter's axis form (no cross products)

@@ -52,7 +52,8 @@ def test_adapter_accepts_reference_types(tmp_path, pkg, O):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which,size,frames,spf,mode", [(2, 64, 2, 4, ""), (0, 48, 3, 2, ""), (2, 56, 2, 3, "multi"), (2, 56, 2, 3, "multi-reduce")])
+@pytest.mark.parametrize("which,size,frames,spf,mode", [(2, 64, 2, 4, ""), (0, 48, 3, 2, ""), (2, 56, 2, 3, "multi"), (2, 56, 2, 3, "multi-reduce"),
+                                                         (2, 56, 3, 16, "multi-frame")])
 def test_host_demo_matches_python_host(pkg, which, size, frames, spf, mode):
     exe = os.path.join(ROOT, "computer-graphics_amd", "host", "host_demo")
     assert os.path.exists(exe), "host_demo is built by __graft_entry__.build()"

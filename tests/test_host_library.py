@@ -151,6 +151,37 @@ def test_scan_unit_planner_groups_walls_and_blocks(pkg, lib):
     assert lib.mipt_plan_scan_units(None, 3, None, None, None) == abi.MIPT_E_INVALID
 
 
+def l_shapes(abi, n, seed=3):
+    """n L-shaped pairs of turned quads (two faces of a turned box that meet in an edge), 4 triangles each,
+    apart from one another: every one of them qualifies as a two-face box unit."""
+    rng = np.random.default_rng(seed)
+    tri_list = []
+    for k in range(n):
+        Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        F = Q * np.array([0.16, 0.11, 0.13])
+        r = np.array([-0.8 + 0.42 * (k % 4), -0.6 + 0.5 * (k // 4), 0.1 * (k % 3)])
+        tri_list += _box(r, F, ((0, 0), (1, 0)))
+    t = np.zeros(len(tri_list), dtype=abi.TRIANGLE_DTYPE)
+    for k, (a, b, c) in enumerate(tri_list):
+        t["v0"][k, :3], t["v1"][k, :3], t["v2"][k, :3] = a, b, c
+        t["v0"][k, 3] = t["v1"][k, 3] = t["v2"][k, 3] = 1.0
+        e1, e2 = np.float32(b) - np.float32(a), np.float32(c) - np.float32(a)
+        nrm = np.cross(e2, e1)
+        t["normal"][k, :3] = nrm / max(np.linalg.norm(nrm), 1e-30)
+        t["normal"][k, 3] = 1.0
+    t["color"] = 0.7
+    return t
+
+
+def test_a_chunk_holds_at_most_seven_box_units(pkg, lib):
+    # a chunk's record carries the number of its box units in three bits: eight two-face boxes in one
+    # chunk of 32 triangles must come out as seven boxes + two pair units, not as a count that wraps to 0
+    api, abi = pkg.api, pkg.abi
+    for n, want_boxes in ((7, 7), (8, 7), (16, 14)):       # 16 L-shapes = two chunks of eight
+        pairs, axis, boxes = api.plan_scan_units(l_shapes(abi, n))
+        assert (pairs, axis, boxes) == (2 * n, 0, want_boxes), (n, pairs, axis, boxes)
+
+
 def test_missing_library_fails_loudly(pkg, tmp_path):
     with pytest.raises(pkg.abi.MiptLibraryMissing):
         pkg.abi.load_library(str(tmp_path / "libmipt.so"))

@@ -173,6 +173,31 @@ def test_bench_launcher_starts_the_ranks(tmp_path, O, pkg, capfd):
     assert bench.spawn_ranks(2, [str(steps), str(warmup), str(spp), out, "fail-on-rank-1"], script=stub) == 7
 
 
+def test_bench_launcher_with_eight_ranks_and_a_rank_that_dies_mid_run(tmp_path, O, pkg, capfd):
+    # the driver's scaling run is 8 ranks: the launcher with 8 CPU stand-in ranks (gloo) -- sample split
+    # 7 over 8 (one rank gets nothing), one JSON line, the 8-rank image -- and then the same with rank 5
+    # dying between two collectives: the launcher ends the seven ranks left waiting in the reduce and
+    # returns the dead rank's exit code instead of hanging
+    import json
+    import time
+    import bench
+    out = str(tmp_path / "total.npy")
+    stub = os.path.join(ROOT, "tests", "bench_rank_stub.py")
+    steps, warmup, spp = 1, 1, 7
+    assert bench.spawn_ranks(8, [str(steps), str(warmup), str(spp), out], script=stub) == 0
+    lines = [l for l in capfd.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 8
+    got = np.load(out).reshape(20, 16, 3)
+    tris = O.load_test_model(2)
+    cam, light = O.default_camera(20), O.default_light(True)
+    params = O.default_params(20, 16, rng_mode=pkg.abi.RNG_COUNTER, seed=9)
+    want, _ = O.render_accumulate(tris, None, cam, light, params, 0, spp * (steps + warmup))
+    assert want.sum() > 0 and np.allclose(got, want, rtol=1e-5, atol=1e-7)
+    t0 = time.time()
+    assert bench.spawn_ranks(8, ["2", "1", str(spp), out, "die-mid-run-on-rank-5"], script=stub) == 9
+    assert time.time() - t0 < 120
+
+
 def test_bench_becomes_the_launcher_for_gpus_above_one(monkeypatch, pkg):
     # the driver's `python bench.py --gpus 8`: no WORLD_SIZE in the environment -> 8 ranks are started
     import bench

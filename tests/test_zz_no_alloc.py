@@ -56,3 +56,39 @@ def test_no_alloc_entry_point_rejects_oversized_calls(pkg, O):
     torch.cuda.synchronize()
     assert torch.equal(ref.view(torch.int32), buf.view(torch.int32))
     sc.close()
+
+
+def test_no_alloc_entry_point_under_graph_capture(pkg, O):
+    # the callers the entry point is for: its three operations (memset of the queue head, path kernel,
+    # ordered sum) are captured into a HIP graph on a side stream and replayed; every replay adds the
+    # captured samples again, exactly as the plain entry point called that often
+    import torch
+    abi, api = pkg.abi, pkg.api
+    tris = O.load_test_model(2)
+    sc = api.Scene(tris)
+    W, H = 160, 96
+    cam, light = O.default_camera(W), O.default_light(True)
+    p = O.default_params(W, H, seed=12, fog_sigma_t=0.1)
+    dev = torch.device("cuda", 0)
+    out = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
+    ref = torch.zeros_like(out)
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            sc.render_accumulate_noalloc_dev(cam, light, p, 0, 32, out)
+    torch.cuda.synchronize()
+    assert not out.any().item()          # capture records, it does not run
+    for _ in range(3):
+        graph.replay()
+        sc.render_accumulate_dev(cam, light, p, 0, 32, ref)
+    torch.cuda.synchronize()
+    assert ref.abs().sum().item() > 0
+    assert torch.equal(ref.view(torch.int32), out.view(torch.int32))
+    with pytest.raises(api.MiptError) as e:     # the counters are scene scratch: not through this entry point
+        ps = O.default_params(W, H, seed=12, flags=abi.FLAG_STATS)
+        sc.render_accumulate_noalloc_dev(cam, light, ps, 0, 16, out)
+    assert e.value.code == abi.MIPT_E_INVALID
+    del graph
+    sc.close()

@@ -10,8 +10,12 @@ at 64 bytes). valu_issue_frac = wave-level VALU instructions x 2 issue cycles / 
 SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64).
 """
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as graft  # noqa: E402
 
 
 def per_kernel(db_path, substr):
@@ -38,7 +42,8 @@ def main():
     for name, avg in db.cursor().execute("select name, average from top_kernels"):
         if substr in name:
             avg_us = avg
-    res = {"kernel": substr, "source": f"{d}: rocprofv3 --kernel-trace --pmc passes of `bench.py --steps 3 --warmup 1 --no-cpu` "
+    # the code these counters belong to: bench.py drops them when the sources have changed since
+    res = {"kernel": substr, "source_hash": graft.kernel_source_hash(), "source": f"{d}: rocprofv3 --kernel-trace --pmc passes of `bench.py --steps 3 --warmup 1 --no-cpu` "
                                        "(tools/profile_round.sh); per launch = sum over dispatches / dispatches"}
     n = lambda t: t[0] / t[1]
     # fetch_scale=1 for kernels whose reads are 64-byte gathers (tree nodes, triangle records): their
