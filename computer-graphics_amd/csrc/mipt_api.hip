@@ -1545,6 +1545,17 @@ extern "C" int mipt_get_stats(MiptScene* s, MiptStats* out) {
             (double)pf[PF_N_FLUSH] / (double)(pf[PF_N_ITERS] ? pf[PF_N_ITERS] : 1),
             (double)pf[PF_N_JOBS] / (double)(pf[PF_N_FLUSH] ? pf[PF_N_FLUSH] : 1),
             (double)pf[PF_N_JOB_LEVELS] / (double)(pf[PF_N_JOBS] ? pf[PF_N_JOBS] : 1));
+    if (pf[PF_W_BURSTS])
+      fprintf(stderr, "[mipt sections] tree walk: %.2f bursts per iteration, %.1f lanes entering; per burst %.2f node rounds at %.1f lanes, "
+                      "%.2f leaf rounds at %.1f lanes; per iteration %.1f lanes begin a ray, %.1f are shaded\n",
+              (double)pf[PF_W_BURSTS] / (double)(pf[PF_N_ITERS] ? pf[PF_N_ITERS] : 1),
+              (double)pf[PF_W_ENTERED] / (double)pf[PF_W_BURSTS],
+              (double)pf[PF_W_NODE_ROUNDS] / (double)pf[PF_W_BURSTS],
+              (double)pf[PF_W_NODE_LANES] / (double)(pf[PF_W_NODE_ROUNDS] ? pf[PF_W_NODE_ROUNDS] : 1),
+              (double)pf[PF_W_LEAF_ROUNDS] / (double)pf[PF_W_BURSTS],
+              (double)pf[PF_W_LEAF_LANES] / (double)(pf[PF_W_LEAF_ROUNDS] ? pf[PF_W_LEAF_ROUNDS] : 1),
+              (double)pf[PF_N_FRESH] / (double)(pf[PF_N_ITERS] ? pf[PF_N_ITERS] : 1),
+              (double)pf[PF_N_READY] / (double)(pf[PF_N_ITERS] ? pf[PF_N_ITERS] : 1));
     fprintf(stderr, "[mipt sections] queries with >= 3 / 4 / 6 candidates: %.2f %% / %.2f %% / %.3f %%\n",
             100.0 * (double)pf[PF_N_GE3] / (double)(pf[PF_N_QUERIES] ? pf[PF_N_QUERIES] : 1),
             100.0 * (double)pf[PF_N_GE4] / (double)(pf[PF_N_QUERIES] ? pf[PF_N_QUERIES] : 1),

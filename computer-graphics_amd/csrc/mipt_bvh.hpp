@@ -671,19 +671,24 @@ __device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, SP sc, BvhRay& 
 template <int KEEP_NUM = BVH_KEEP_NUM, int KEEP_DEN = BVH_KEEP_DEN, bool SET_ASIDE = true, typename STK, typename SP>
 __device__ __forceinline__ void bvh_burst(BvhTrav& T, BvhMem& M, const STK& stack, SP sc,
                                           const BvhNode* __restrict__ nodes, BvhRay& r, bool shadow, float max_t,
-                                          uint32_t& overflow) {
+                                          uint32_t& overflow, uint32_t* round_ctr = nullptr) {
+  // round_ctr (developer builds): LDS counters {bursts, lanes entered, node rounds, lanes in them, leaf rounds, lanes in them}
   const int entered = __popcll(__ballot(T.cur != BVH_DONE));
+  const bool tally = round_ctr && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1;
+  if (tally && entered) { atomicAdd(round_ctr + 0, 1u); atomicAdd(round_ctr + 1, (uint32_t)entered); }
   while (T.cur != BVH_DONE) {
     if (SET_ASIDE && T.cur < 0 && T.pend == BVH_DONE && T.sp > 0) { T.pend = T.cur; T.cur = stack.pop(T.sp); }
     const int n_node = __popcll(__ballot(T.cur >= 0));
     const int n_leaf = __popcll(__ballot(T.pend != BVH_DONE || T.cur < 0));
     if (MIPT_BVH_VOTE_NODE * n_node >= MIPT_BVH_VOTE_LEAF * n_leaf) {
+      if (round_ctr && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) { atomicAdd(round_ctr + 2, 1u); atomicAdd(round_ctr + 3, (uint32_t)n_node); }
       if (T.cur >= 0) {
         const BvhNode N = nodes[T.cur];
         r.n_nodes++;
         if (!bvh_step(N, r.oo, r.inv, T.bound, T.cur, stack, T.sp)) { overflow++; T.redo = true; T.cur = T.pend = BVH_DONE; }
       }
     } else {
+      if (round_ctr && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) { atomicAdd(round_ctr + 4, 1u); atomicAdd(round_ctr + 5, (uint32_t)n_leaf); }
       int leaf = T.pend;
       if (leaf != BVH_DONE) {
         T.pend = BVH_DONE;

@@ -75,7 +75,9 @@ struct PathArgs {
 enum ProfSection {
   PF_QUEUE = 0, PF_RAYGEN, PF_PHASE1, PF_PHASE2, PF_HIT, PF_TERMINAL, PF_SCATTER, PF_DIFFUSE, PF_MIRROR,
   PF_GLASS, PF_RENORM, PF_UNWIND, PF_N_QUERIES, PF_N_CANDS, PF_N_ROUNDS, PF_N_GE3, PF_N_GE4, PF_N_GE6,
-  PF_N_ITERS, PF_N_FLUSH, PF_N_JOBS, PF_N_JOB_LEVELS, PF_COUNT
+  PF_N_ITERS, PF_N_FLUSH, PF_N_JOBS, PF_N_JOB_LEVELS,
+  PF_W_BURSTS, PF_W_ENTERED, PF_W_NODE_ROUNDS, PF_W_NODE_LANES, PF_W_LEAF_ROUNDS, PF_W_LEAF_LANES,  // tree walk, in this order
+  PF_N_READY, PF_N_FRESH, PF_COUNT
 };
 #ifdef MIPT_PROFILE_SECTIONS
 struct Prof {
@@ -138,11 +140,14 @@ template <> struct TagType<SCENE_LINEAR_LDS> { typedef uint8_t T; };
 template <> struct TagType<SCENE_LINEAR> { typedef uint16_t T; };
 // Linear-scan scenes without spheres finish their lit paths in batches (see k_paths): two vertex
 // stacks, two terminal records and two radiance sums per lane.
-// Scenes too large for 16-bit tags (a tree, or the linear scan forced onto a big scene) keep their
-// vertex stacks in global memory as RECORDS -- the vertex's normal, colour and kind, 32 bytes -- so
-// the completion needs no index into the scene and no second stack of sphere normals, and the LDS
-// holds two terminal records and two sums per lane whatever the scene's size: they always finish in
-// batches.
+// The linear scan forced onto a scene too large for 16-bit tags (SCENE_LINEAR_BIG) keeps its vertex
+// stacks in global memory as RECORDS -- the vertex's normal, colour and kind, 32 bytes -- so the
+// completion needs no index into the scene and no second stack of sphere normals, and the LDS holds
+// two terminal records and two sums per lane whatever the scene's size: such scenes always finish in
+// batches. Tree scenes can be built the same way (-DMIPT_TREE_VSTACK=1) and were measured so: the
+// batched completion saves them at most 5 % (the bound: a build that skips the completion altogether)
+// and the stores and loads of the records cost as much -- 0 ... -8 % paths/s on four scenes against
+// 32-bit tags in LDS with every lit path completed at once, which is what they keep.
 #ifndef MIPT_TREE_VSTACK
 #define MIPT_TREE_VSTACK 0
 #endif
@@ -542,7 +547,8 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   //   11 c + 3      the item's output slot (index into a.partial, divided by 3)
   //   11 b + 4..7   direction of the path's last segment
   //   11 b + 8..10  terminal vertex: clamped cosine to the light, distance to the light, primitive
-  // Linear-scan scenes without spheres use both sets (deferred completion, below), the others one.
+  // Linear-scan scenes without spheres, and scenes with global vertex stacks, use both sets (deferred
+  // completion, below), the others one.
   typedef typename TagType<KIND>::T TagT;
   constexpr uint32_t TAGV_GLASS = (uint32_t)(TagT)TAG_GLASS, TAGV_FOG = (uint32_t)(TagT)TAG_FOG;
   constexpr bool GSTACK = (MIPT_TREE_VSTACK && KIND == SCENE_BVH) || KIND == SCENE_LINEAR_BIG;  // vstack_kind(KIND)
@@ -725,11 +731,12 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       // (the scene's fields are fetched from the argument block where the walk uses them: held in scalar
       // registers from the kernel's entry on they crowd out the loop's own and are spilled)
       BvhRay r = bvh_ray(late_args()->sc.scale, o, d);  // o, d stay put while the lane walks
-      if (!walking) { bvh_begin(trav, trav_mem, &late_args()->sc, r, shadow, lim0); walking = true; }
+      if (!walking) { prof.count(PF_N_FRESH, 1u); bvh_begin(trav, trav_mem, &late_args()->sc, r, shadow, lim0); walking = true; }
       prof.mark(PF_PHASE1);
       {
         const PathArgs MIPT_CONST* kb = late_args();
-        bvh_burst(trav, trav_mem, StackLds{bvh_lds_stack + tid, trav_mem.stack}, &kb->sc, kb->sc.bvh, r, shadow, lim0, overflow);
+        bvh_burst(trav, trav_mem, StackLds{bvh_lds_stack + tid, trav_mem.stack}, &kb->sc, kb->sc.bvh, r, shadow, lim0, overflow,
+                  prof.lds ? prof.lds + PF_W_BURSTS : nullptr);
       }
       n_tests = r.n_leaves; n_nodes = r.n_nodes;
       prof.mark(PF_PHASE2);
@@ -754,6 +761,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       ready = true;
     }
     }  // if (have)
+    prof.count(PF_N_READY, ready ? 1u : 0u);
     bool path_done = false;
     bool lit = false;  // the path ended at a terminal vertex the light reaches: a job for the completion below
     if (ready) {
@@ -977,7 +985,8 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
     // buffer back: it ends another lit path, or it is about to start an item on the sum context
     // its job still adds to. A lane's jobs run in the order of its paths, so the item's sum is
     // formed in sample order as before. Scenes with spheres or a tree keep one buffer and compute
-    // the job at once (their stacks are too large to double in LDS).
+    // the job at once (their stacks are too large to double in LDS; see vstack_kind for what moving
+    // them to global memory measured).
     const bool want_job = path_done && lit;
     const bool item_end = path_done && s + 1 >= s_end;
     const bool pend = (js & JS_PEND) != 0;
