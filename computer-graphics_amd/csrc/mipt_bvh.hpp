@@ -560,10 +560,16 @@ __device__ __forceinline__ BvhRay bvh_ray(float scene_scale, V4 o, V4 d) {
 
 // could the reference accept this triangle at all? intersections.cpp:25 with min = FLT_MAX, :27
 // FILTER = false: the caller has run the candidate filter on this triangle already (scan units)
+template <bool FILTER = true>
+__device__ __forceinline__ bool bvh_leaf_rec(const TriRec& T, const BvhRay& r, float& t, float& z, float& x1, float& x2);
 template <bool FILTER = true, typename SP>
 __device__ __forceinline__ bool bvh_leaf(SP sc, const BvhRay& r, int i, float& t, float& z,
                                          float& x1, float& x2) {
   const TriRec T = sc->tris[i];
+  return bvh_leaf_rec<FILTER>(T, r, t, z, x1, x2);
+}
+template <bool FILTER>
+__device__ __forceinline__ bool bvh_leaf_rec(const TriRec& T, const BvhRay& r, float& t, float& z, float& x1, float& x2) {
   if (FILTER && !tri_candidate(&T, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.Dm)) return false;
   float x0;
   tri_eval(&T, r.o.x, r.o.y, r.o.z, r.px, r.py, r.pz, t, x0, x1, x2);
@@ -623,9 +629,10 @@ __device__ __forceinline__ void bvh_take(BvhTrav& T, BvhMem& M, const BvhRay& r,
   }
 }
 
+// big_recs: null, or the records of the big triangles in list order in fast memory (the path kernel's LDS copy)
 template <typename SP>
 __device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, SP sc, BvhRay& r, bool shadow,
-                                          float max_t) {
+                                          float max_t, const TriRec* big_recs = nullptr) {
   T.cur = sc->bvh_root;
   T.pend = BVH_DONE;
   T.sp = 0; T.n_list = 0;
@@ -642,10 +649,14 @@ __device__ __forceinline__ void bvh_begin(BvhTrav& T, BvhMem& M, SP sc, BvhRay& 
     uint32_t mask = unit_mask(sc->units + base, r.o, r.d, r.Dm);
     r.n_leaves += (uint32_t)__popc(mask);
     while (mask != 0 && !(T.redo || T.hit)) {
-      const int i = sc->big_ids[base + __ffs((int)mask) - 1];
+      const int slot = base + __ffs((int)mask) - 1;
+      const int i = sc->big_ids[slot];
       mask &= mask - 1u;
       float t, z, x1, x2;
-      if (bvh_leaf<false>(sc, r, i, t, z, x1, x2)) bvh_take(T, M, r, shadow, max_t, i, t, z, x1, x2);
+      bool could;
+      if (big_recs) { const TriRec Tb = big_recs[slot]; could = bvh_leaf_rec<false>(Tb, r, t, z, x1, x2); }
+      else could = bvh_leaf<false>(sc, r, i, t, z, x1, x2);
+      if (could) bvh_take(T, M, r, shadow, max_t, i, t, z, x1, x2);
     }
   }
   // a big triangle may have ended the query (any-hit found, or redo) before the tree had a say

@@ -507,6 +507,10 @@ __global__ __launch_bounds__(BLOCK) MIPT_BATCH_OCC void k_bvh_batch(DeviceScene 
 #ifndef MIPT_TREE_WAVES_PER_EU
 #define MIPT_TREE_WAVES_PER_EU 4
 #endif
+// how many big triangles of a tree scene have their records staged in LDS by the path kernel (0: none)
+#ifndef MIPT_BIG_LDS
+#define MIPT_BIG_LDS 16
+#endif
 #define MIPT_PATHS_OCC                                                                              \
   __attribute__((amdgpu_waves_per_eu(KIND == SCENE_BVH ? MIPT_TREE_WAVES_PER_EU : MIPT_WAVES_PER_EU, \
                                      KIND == SCENE_BVH ? MIPT_TREE_WAVES_PER_EU : MIPT_WAVES_PER_EU)))
@@ -606,6 +610,17 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
   __shared__ int bvh_lds_stack[(BVH && BVH_LDS_STACK ? BVH_LDS_STACK : 0) * BLOCK + 1];
   trav.cur = BVH_DONE;
   bool walking = false;
+  // tree scenes: the records of the big triangles (the room's walls, tested before every walk) in LDS,
+  // when there are few enough of them: the candidates' tests then start without a trip to memory
+  __shared__ TriRec big_lds[BVH && MIPT_BIG_LDS > 0 ? MIPT_BIG_LDS : 1];
+  const TriRec* big_recs = nullptr;
+  if (BVH && MIPT_BIG_LDS > 0 && a.sc.n_big > 0 && a.sc.n_big <= MIPT_BIG_LDS) {
+    uint32_t* dst = reinterpret_cast<uint32_t*>(big_lds);
+    for (int i = tid; i < a.sc.n_big * 16; i += BLOCK)
+      dst[i] = reinterpret_cast<const uint32_t*>(a.sc.tris + a.sc.big_ids[i >> 4])[i & 15];
+    __syncthreads();
+    big_recs = big_lds;
+  }
   // per-primitive records the shading reads by hit index: from LDS for small scenes
   const TriRec* tri_tab = a.sc.tris;
   const ShadeRec* shade_tab = a.sc.shade;
@@ -731,7 +746,7 @@ __global__ __launch_bounds__(BLOCK) MIPT_PATHS_OCC void k_paths(const PathArgs a
       // (the scene's fields are fetched from the argument block where the walk uses them: held in scalar
       // registers from the kernel's entry on they crowd out the loop's own and are spilled)
       BvhRay r = bvh_ray(late_args()->sc.scale, o, d);  // o, d stay put while the lane walks
-      if (!walking) { prof.count(PF_N_FRESH, 1u); bvh_begin(trav, trav_mem, &late_args()->sc, r, shadow, lim0); walking = true; }
+      if (!walking) { prof.count(PF_N_FRESH, 1u); bvh_begin(trav, trav_mem, &late_args()->sc, r, shadow, lim0, big_recs); walking = true; }
       prof.mark(PF_PHASE1);
       {
         const PathArgs MIPT_CONST* kb = late_args();
