@@ -88,7 +88,7 @@ EXPORTS = [
     "mipt_scene_destroy", "mipt_closest_hit", "mipt_any_hit", "mipt_render_accumulate",
     "mipt_resolve_argb", "mipt_trace_paths", "mipt_closest_hit_dev", "mipt_any_hit_dev",
     "mipt_render_accumulate_dev", "mipt_resolve_argb_dev", "mipt_get_stats", "mipt_path_key",
-    "mipt_load_test_model", "mipt_default_camera", "mipt_default_light", "mipt_debug_selfcheck", "mipt_scene_has_bvh", "mipt_scene_pair_units", "mipt_scene_axis_pair_units", "mipt_scene_box_units", "mipt_plan_scan_units", "mipt_load_obj", "mipt_normalise_triangles", "mipt_save_bmp", "mipt_frame_create", "mipt_frame_destroy", "mipt_frame_reset",
+    "mipt_load_test_model", "mipt_default_camera", "mipt_default_light", "mipt_debug_selfcheck", "mipt_scene_has_bvh", "mipt_scene_tree_info", "mipt_scene_pair_units", "mipt_scene_axis_pair_units", "mipt_scene_box_units", "mipt_plan_scan_units", "mipt_load_obj", "mipt_normalise_triangles", "mipt_save_bmp", "mipt_frame_create", "mipt_frame_destroy", "mipt_frame_reset",
     "mipt_frame_add_samples", "mipt_frame_present", "mipt_frame_read_pixels", "mipt_frame_samples",
     "mipt_render_accumulate_noalloc_dev", "mipt_scene_create_opts",
     "mipt_multi_create", "mipt_multi_destroy", "mipt_multi_device_count", "mipt_multi_render_accumulate",
@@ -182,6 +182,7 @@ def load_library(path=None):
     lib.mipt_path_key.restype = C.c_uint32
     lib.mipt_debug_selfcheck.argtypes = [vp, C.c_uint64, C.c_uint32, P(C.c_uint64 * 8)]
     lib.mipt_scene_has_bvh.argtypes = [vp, P(C.c_uint64), P(C.c_double)]
+    lib.mipt_scene_tree_info.argtypes = [vp, P(C.c_int), P(C.c_int), P(C.c_float)]
     lib.mipt_scene_pair_units.argtypes = [vp]
     lib.mipt_scene_axis_pair_units.argtypes = [vp]
     lib.mipt_scene_box_units.argtypes = [vp]

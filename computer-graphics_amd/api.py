@@ -214,6 +214,14 @@ class Scene:
         has = self._lib.mipt_scene_has_bvh(self._h, C.byref(n), C.byref(ms))
         return bool(has), int(n.value), float(ms.value)
 
+    def tree_info(self):
+        """(the tree came from the clustering rather than the radix tree, the clustered tree's depth,
+        its surface-area cost over the radix tree's); None without a tree"""
+        c, d, r = C.c_int(), C.c_int(), C.c_float()
+        if not self._lib.mipt_scene_tree_info(self._h, C.byref(c), C.byref(d), C.byref(r)):
+            return None
+        return bool(c.value), int(d.value), float(r.value)
+
     def pair_units(self):
         """pairs of coplanar triangles the linear scan's candidate filter merged"""
         return int(self._lib.mipt_scene_pair_units(self._h))

@@ -117,6 +117,9 @@ struct MiptScene {
   int* d_big = nullptr;
   int n_tree_tris = 0;
   int n_wide_nodes = 0;
+  bool bvh_radix_tree = false;  // the binary tree came from the radix-tree fallback, not from the clustering
+  int bvh_depth = 0, bvh_rounds = 0;  // of the clustering (diagnostics)
+  float bvh_cost_ratio = 0.f;         // surface-area cost of the clustered tree / the radix tree's
   double bvh_build_ms = 0.0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // recorded after every launch that uses the scene's scratch memory (queue heads, item sums,
@@ -208,12 +211,114 @@ struct StageCursor {
   }
 };
 
-// LBVH over the triangles listed in `subset` (n >= 2 of them): bounds -> Morton keys -> radix sort
-// -> binary topology -> refit waves -> collapse into four-wide nodes, level by level. Everything runs on the null stream of the scene's device; the tree
-// is final on return.
+// The binary tree by locally-ordered clustering over the sorted triangles (k_ploc_* in mipt_bvh.hpp).
+// On success *root is the root's index in `bin`; *root = -1 (and MIPT_OK) when the tree came out deeper
+// than PLOC_MAX_DEPTH, i.e. deeper than the walk's stack is sized for: the caller builds the radix tree
+// instead. *depth, *rounds: what the clustering did (diagnostics).
+static int build_ploc(const Aabb* tri_box, const int* sorted_ids, int n, BvhBin* bin, int* root, int* depth, int* rounds) {
+  *root = -1;
+  DevBuf cbox0, cbox1, cid0, cid1, nn, keep, pos, counter, tmp;
+  HIP_TRY(cbox0.alloc((size_t)n * sizeof(Aabb))); HIP_TRY(cbox1.alloc((size_t)n * sizeof(Aabb)));
+  HIP_TRY(cid0.alloc((size_t)n * 8)); HIP_TRY(cid1.alloc((size_t)n * 8));
+  HIP_TRY(nn.alloc((size_t)n * 4)); HIP_TRY(keep.alloc((size_t)n * 4)); HIP_TRY(pos.alloc((size_t)n * 4));
+  HIP_TRY(counter.alloc(4));
+  HIP_TRY(hipMemset(counter.p, 0, 4));
+  size_t tmp_bytes = 0;
+  HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, keep.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)n,
+                                  rocprim::plus<uint32_t>(), nullptr));
+  HIP_TRY(tmp.alloc(tmp_bytes));
+  Aabb* cb = cbox0.as<Aabb>();
+  Aabb* cb2 = cbox1.as<Aabb>();
+  int2* ci = cid0.as<int2>();
+  int2* ci2 = cid1.as<int2>();
+  hipLaunchKernelGGL(k_ploc_init, dim3(grid_for(n)), dim3(BLOCK), 0, nullptr, tri_box, sorted_ids, n, cb, ci);
+  HIP_TRY(hipGetLastError());
+  int m = n;
+  int round = 0;
+  for (; m > 1; ++round) {
+    if (round >= 4096) return fail(MIPT_E_HIP, "tree clustering did not finish in %d rounds (%d clusters left)", round, m);
+    hipLaunchKernelGGL(k_ploc_nearest, dim3(grid_for(m)), dim3(BLOCK), 0, nullptr, cb, m, nn.as<int>());
+    hipLaunchKernelGGL(k_ploc_merge, dim3(grid_for(m)), dim3(BLOCK), 0, nullptr, cb, ci, nn.as<int>(), m, bin,
+                       counter.as<int>(), keep.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    size_t bytes = tmp_bytes;
+    HIP_TRY(rocprim::exclusive_scan(tmp.p, bytes, keep.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)m,
+                                    rocprim::plus<uint32_t>(), nullptr));
+    hipLaunchKernelGGL(k_ploc_compact, dim3(grid_for(m)), dim3(BLOCK), 0, nullptr, cb, ci, keep.as<uint32_t>(),
+                       pos.as<uint32_t>(), m, cb2, ci2);
+    HIP_TRY(hipGetLastError());
+    uint32_t last_pos = 0, last_keep = 0;
+    HIP_TRY(hipMemcpy(&last_pos, pos.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&last_keep, keep.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost));
+    const int next = (int)(last_pos + last_keep);
+    if (next < 1 || next >= m) return fail(MIPT_E_HIP, "tree clustering stalled at %d clusters (round %d)", m, round);
+    m = next;
+    std::swap(cb, cb2);
+    std::swap(ci, ci2);
+  }
+  int n_nodes = 0;
+  int2 top = make_int2(-1, 0);
+  HIP_TRY(hipMemcpy(&n_nodes, counter.p, 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&top, ci, 8, hipMemcpyDeviceToHost));
+  if (n_nodes != n - 1 || top.x < 0 || top.x >= n - 1)
+    return fail(MIPT_E_HIP, "tree clustering ended with %d nodes of %d, root %d", n_nodes, n - 1, top.x);
+  *depth = top.y;
+  *rounds = round;
+  if (top.y <= PLOC_MAX_DEPTH) *root = top.x;
+  return MIPT_OK;
+}
+
+// The radix tree over the sorted keys (Karras 2012) with its boxes: topology in one launch, then refit
+// waves from the leaves up. The root is node 0.
+static int build_radix_tree(const unsigned long long* keys, const int* sorted_ids, const Aabb* tri_box, int n, BvhBin* bin) {
+  DevBuf node_box, ready, done;
+  HIP_TRY(node_box.alloc((size_t)n * sizeof(Aabb)));
+  HIP_TRY(ready.alloc((size_t)n * 2));
+  HIP_TRY(done.alloc(4));
+  hipLaunchKernelGGL(k_bvh_topology, dim3(grid_for(n - 1)), dim3(BLOCK), 0, nullptr, keys, sorted_ids, n, bin);
+  HIP_TRY(hipGetLastError());
+  // refit: ready flags ping-pong between the two halves of `ready`; the count of finished nodes
+  // is read back once per wave (a tree over sorted Morton keys is ~log2(n) + a few levels deep)
+  HIP_TRY(hipMemset(ready.p, 0, (size_t)n * 2));
+  HIP_TRY(hipMemset(done.p, 0, 4));
+  unsigned char* r0 = ready.as<unsigned char>();
+  unsigned char* r1 = r0 + n;
+  int n_done = 0, prev = -1, waves = 0;
+  while (n_done < n - 1) {
+    if (n_done == prev || ++waves > 4096)
+      return fail(MIPT_E_HIP, "LBVH refit stalled at %d of %d nodes after %d waves", n_done, n - 1, waves);
+    prev = n_done;
+    hipLaunchKernelGGL(k_bvh_refit, dim3(grid_for(n - 1)), dim3(BLOCK), 0, nullptr, bin, n, tri_box,
+                       node_box.as<Aabb>(), r1, r0, done.as<int>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(&n_done, done.p, 4, hipMemcpyDeviceToHost));
+    std::swap(r0, r1);
+  }
+  return MIPT_OK;
+}
+
+// Surface-area cost of a binary tree of n - 1 nodes (k_bin_cost)
+static int tree_cost(const BvhBin* bin, int n, double* cost) {
+  const int blocks = grid_for(n - 1);
+  DevBuf partial;
+  HIP_TRY(partial.alloc((size_t)blocks * 8));
+  hipLaunchKernelGGL(k_bin_cost, dim3(blocks), dim3(BLOCK), 0, nullptr, bin, n - 1, partial.as<double>());
+  HIP_TRY(hipGetLastError());
+  std::vector<double> h(blocks);
+  HIP_TRY(hipMemcpy(h.data(), partial.p, (size_t)blocks * 8, hipMemcpyDeviceToHost));
+  double c = 0.0;
+  for (double v : h) c += v;
+  *cost = c;
+  return MIPT_OK;
+}
+
+// Tree over the triangles listed in `subset` (n >= 2 of them): bounds -> Morton keys -> radix sort ->
+// binary tree (locally-ordered clustering; the radix tree over the keys + refit waves as the fallback)
+// -> collapse into four-wide nodes, level by level. Everything runs on the null stream of the scene's
+// device; the tree is final on return.
 static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
   const int n = (int)subset.size();
-  DevBuf box, cen, scene, keys, ids, keys2, ids2, node_box, ready, done, tmp, sub, bin, wide, front;
+  DevBuf box, cen, scene, keys, ids, keys2, ids2, tmp, sub, bin, bin_b, wide, front;
   HIP_TRY(sub.alloc((size_t)n * 4));
   HIP_TRY(hipMemcpy(sub.p, subset.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   HIP_TRY(box.alloc((size_t)s->d.n_tris * sizeof(Aabb)));
@@ -221,9 +326,6 @@ static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
   HIP_TRY(scene.alloc(6 * 4));
   HIP_TRY(keys.alloc((size_t)n * 8)); HIP_TRY(keys2.alloc((size_t)n * 8));
   HIP_TRY(ids.alloc((size_t)n * 4)); HIP_TRY(ids2.alloc((size_t)n * 4));
-  HIP_TRY(node_box.alloc((size_t)n * sizeof(Aabb)));
-  HIP_TRY(ready.alloc((size_t)n * 2));
-  HIP_TRY(done.alloc(4));
   HIP_TRY(bin.alloc((size_t)(n - 1) * sizeof(BvhBin)));
   HIP_TRY(wide.alloc((size_t)(n - 1) * sizeof(BvhNode)));  // one wide node per binary node at most
   HIP_TRY(front.alloc((size_t)n * 2 * sizeof(int2)));
@@ -247,25 +349,43 @@ static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
   HIP_TRY(tmp.alloc(tmp_bytes));
   HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<unsigned long long>(), keys2.as<unsigned long long>(),
                                     ids.as<int>(), ids2.as<int>(), (size_t)n, 0, 63, nullptr));
-  hipLaunchKernelGGL(k_bvh_topology, dim3(grid_for(n - 1)), dim3(BLOCK), 0, nullptr, keys2.as<unsigned long long>(),
-                     ids2.as<int>(), n, bin.as<BvhBin>());
-  HIP_TRY(hipGetLastError());
-  // refit: ready flags ping-pong between the two halves of `ready`; the count of finished nodes
-  // is read back once per wave (a tree over sorted Morton keys is ~log2(n) + a few levels deep)
-  HIP_TRY(hipMemset(ready.p, 0, (size_t)n * 2));
-  HIP_TRY(hipMemset(done.p, 0, 4));
-  unsigned char* r0 = ready.as<unsigned char>();
-  unsigned char* r1 = r0 + n;
-  int n_done = 0, prev = -1, waves = 0;
-  while (n_done < n - 1) {
-    if (n_done == prev || ++waves > 4096)
-      return fail(MIPT_E_HIP, "LBVH refit stalled at %d of %d nodes after %d waves", n_done, n - 1, waves);
-    prev = n_done;
-    hipLaunchKernelGGL(k_bvh_refit, dim3(grid_for(n - 1)), dim3(BLOCK), 0, nullptr, bin.as<BvhBin>(), n, box.as<Aabb>(),
-                       node_box.as<Aabb>(), r1, r0, done.as<int>());
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(&n_done, done.p, 4, hipMemcpyDeviceToHost));
-    std::swap(r0, r1);
+  int bin_root = -1;
+  bool radix = !MIPT_BVH_PLOC;
+#ifdef MIPT_DEV_SWITCHES
+  { const char* e = getenv("MIPT_RADIX_TREE"); if (e && e[0] == '1') radix = true; }  // developer build only
+#endif
+  if (!radix) {
+    const int rc = build_ploc(box.as<Aabb>(), ids2.as<int>(), n, bin.as<BvhBin>(), &bin_root, &s->bvh_depth, &s->bvh_rounds);
+    if (rc != MIPT_OK) return rc;
+    radix = bin_root < 0;
+    if (!radix) {
+      // both trees, and the one with the lower surface-area cost is kept: clustering wins on meshes,
+      // the radix tree on evenly scattered small triangles, where splitting space in the middle is
+      // already the best there is
+      HIP_TRY(bin_b.alloc((size_t)(n - 1) * sizeof(BvhBin)));
+      const int rr = build_radix_tree(keys2.as<unsigned long long>(), ids2.as<int>(), box.as<Aabb>(), n, bin_b.as<BvhBin>());
+      if (rr != MIPT_OK) return rr;
+      double c_ploc = 0.0, c_radix = 0.0;
+      const int r1 = tree_cost(bin.as<BvhBin>(), n, &c_ploc), r2 = tree_cost(bin_b.as<BvhBin>(), n, &c_radix);
+      if (r1 != MIPT_OK) return r1;
+      if (r2 != MIPT_OK) return r2;
+      s->bvh_cost_ratio = c_radix > 0.0 ? (float)(c_ploc / c_radix) : 0.f;
+      if (!(c_ploc < c_radix)) {
+        std::swap(bin.p, bin_b.p);
+        bin_root = 0;
+        s->bvh_radix_tree = true;
+      }
+    }
+#ifdef MIPT_DEV_SWITCHES
+    fprintf(stderr, "[mipt tree] %d triangles: clustering %d rounds, depth %d, cost %.3f of the radix tree's%s\n", n, s->bvh_rounds,
+            s->bvh_depth, s->bvh_cost_ratio, radix || s->bvh_radix_tree ? " -> radix tree" : "");
+#endif
+  }
+  if (radix) {
+    s->bvh_radix_tree = true;
+    bin_root = 0;
+    const int rc = build_radix_tree(keys2.as<unsigned long long>(), ids2.as<int>(), box.as<Aabb>(), n, bin.as<BvhBin>());
+    if (rc != MIPT_OK) return rc;
   }
   // collapse: the frontier holds (binary node, wide slot) pairs of one level; `done` is reused as
   // {size of the next frontier, wide nodes allocated}
@@ -273,7 +393,7 @@ static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
   HIP_TRY(counters.alloc(8));
   int2* f0 = front.as<int2>();
   int2* f1 = f0 + n;
-  const int2 root_entry = make_int2(0, 0);
+  const int2 root_entry = make_int2(bin_root, 0);
   HIP_TRY(hipMemcpy(f0, &root_entry, sizeof root_entry, hipMemcpyHostToDevice));
   int n_front = 1, n_wide = 1, levels = 0;
   while (n_front > 0) {
@@ -944,6 +1064,17 @@ extern "C" int mipt_scene_has_bvh(MiptScene* s, uint64_t* n_nodes, double* build
   if (!s || !s->d.bvh) return 0;
   if (n_nodes) *n_nodes = (uint64_t)s->n_wide_nodes;
   if (build_ms) *build_ms = s->bvh_build_ms;
+  return 1;
+}
+
+extern "C" int mipt_scene_tree_info(MiptScene* s, int* clustered, int* depth, float* cost_ratio) {
+  if (clustered) *clustered = 0;
+  if (depth) *depth = 0;
+  if (cost_ratio) *cost_ratio = 0.f;
+  if (!s || !s->d.bvh) return 0;
+  if (clustered) *clustered = s->bvh_radix_tree ? 0 : 1;
+  if (depth) *depth = s->bvh_depth;
+  if (cost_ratio) *cost_ratio = s->bvh_cost_ratio;
   return 1;
 }
 

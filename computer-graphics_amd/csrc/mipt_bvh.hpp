@@ -233,6 +233,120 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_refit(BvhBin* __restrict__ nodes,
   atomicAdd(n_done, 1);
 }
 
+// ---------------------------------------------------------------------------------------
+// Binary tree by parallel locally-ordered clustering (Meister & Bittner 2018, "Parallel Locally-Ordered
+// Clustering for Bounding Volume Hierarchy Construction"): bottom-up agglomeration along the Morton
+// order. Every cluster looks at its PLOC_RADIUS neighbours on either side for the one whose union
+// with it has the smallest surface; two clusters that choose each other merge into a new node; the
+// survivors are compacted in order; repeat until one is left. The surfaces of the boxes, not the bits
+// of the keys, decide what is grouped, which costs a ray a third fewer nodes on a mesh than the radix
+// tree over the same keys. Depth: every cluster carries the depth of its subtree, and the builder falls
+// back to the radix tree (whose depth is bounded by its key length) if the finished tree is deeper than
+// the walk's stack allows.
+#ifndef MIPT_BVH_PLOC
+#define MIPT_BVH_PLOC 1
+#endif
+#ifndef MIPT_BVH_PLOC_RADIUS
+#define MIPT_BVH_PLOC_RADIUS 16
+#endif
+constexpr int PLOC_RADIUS = MIPT_BVH_PLOC_RADIUS;
+constexpr int PLOC_MAX_DEPTH = 47;  // binary levels: the walk's stack holds 3 entries for each of 48 four-wide levels
+
+__device__ __forceinline__ float aabb_union_area(const Aabb& a, const Aabb& b) {
+  const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
+  const float dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
+  const float dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+  return dx * dy + dy * dz + dz * dx;  // the same bits whichever box comes first
+}
+
+// the leaves as clusters, in Morton order: cluster i = triangle ids[i] with its padded box
+__global__ __launch_bounds__(BLOCK) void k_ploc_init(const Aabb* __restrict__ tri_box, const int* __restrict__ ids, int n,
+                                                     Aabb* __restrict__ cbox, int2* __restrict__ cid) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  cbox[i] = tri_box[ids[i]];
+  cid[i] = make_int2(-1 - ids[i], 0);  // (reference, depth of the subtree)
+}
+
+// nearest neighbour within the radius; of equally near ones the lowest position. (With a symmetric
+// distance and this tie rule the lowest-positioned cluster among those at the globally smallest
+// distance and its choice choose each other: every round merges at least one pair.)
+__global__ __launch_bounds__(BLOCK) void k_ploc_nearest(const Aabb* __restrict__ cbox, int m, int* __restrict__ nn) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= m) return;
+  const Aabb a = cbox[i];
+  const int lo = i - PLOC_RADIUS > 0 ? i - PLOC_RADIUS : 0, hi = i + PLOC_RADIUS < m - 1 ? i + PLOC_RADIUS : m - 1;
+  float best = __builtin_inff();
+  int bj = -1;
+  for (int j = lo; j <= hi; ++j) {
+    if (j == i) continue;
+    const float d = aabb_union_area(a, cbox[j]);
+    if (d < best || bj < 0) { best = d; bj = j; }
+  }
+  nn[i] = bj;
+}
+
+// mutual choices merge: the lower position keeps the merged cluster (a new binary node), the higher
+// one leaves; keep[i] = 1 for every cluster that goes on to the next round
+__global__ __launch_bounds__(BLOCK) void k_ploc_merge(Aabb* __restrict__ cbox, int2* __restrict__ cid,
+                                                      const int* __restrict__ nn, int m, BvhBin* __restrict__ bin,
+                                                      int* __restrict__ n_nodes, uint32_t* __restrict__ keep) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= m) return;
+  const int j = nn[i];
+  if (j < 0 || nn[j] != i) { keep[i] = 1u; return; }
+  if (i > j) { keep[i] = 0u; return; }
+  const Aabb a = cbox[i], b = cbox[j];
+  const int k = atomicAdd(n_nodes, 1);
+  BvhBin N;
+  Aabb u;
+  for (int c = 0; c < 3; ++c) {
+    N.lmin[c] = a.lo[c]; N.lmax[c] = a.hi[c];
+    N.rmin[c] = b.lo[c]; N.rmax[c] = b.hi[c];
+    u.lo[c] = fminf(a.lo[c], b.lo[c]);
+    u.hi[c] = fmaxf(a.hi[c], b.hi[c]);
+  }
+  const int2 ci = cid[i], cj = cid[j];
+  N.left = ci.x; N.right = cj.x;
+  N.pad0 = 0; N.pad1 = 0;
+  bin[k] = N;
+  cbox[i] = u;  // (only this thread reads or writes clusters i and j in this launch)
+  cid[i] = make_int2(k, 1 + (ci.y > cj.y ? ci.y : cj.y));
+  keep[i] = 1u;
+}
+
+// the survivors, in order: pos = exclusive prefix sum of keep
+__global__ __launch_bounds__(BLOCK) void k_ploc_compact(const Aabb* __restrict__ cbox, const int2* __restrict__ cid,
+                                                        const uint32_t* __restrict__ keep, const uint32_t* __restrict__ pos,
+                                                        int m, Aabb* __restrict__ cbox_out, int2* __restrict__ cid_out) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= m || !keep[i]) return;
+  cbox_out[pos[i]] = cbox[i];
+  cid_out[pos[i]] = cid[i];
+}
+
+// Surface-area cost of a binary tree: the sum of the surfaces of all child boxes (up to the common
+// factor of the root's surface, the expected number of boxes a random line through the scene meets).
+// One partial sum per block, added in a fixed order: the same tree always gets the same cost.
+__global__ __launch_bounds__(BLOCK) void k_bin_cost(const BvhBin* __restrict__ bin, int n_nodes, double* __restrict__ partial) {
+  __shared__ double part[BLOCK];
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  double c = 0.0;
+  if (i < n_nodes) {
+    const BvhBin B = bin[i];
+    const float lx = B.lmax[0] - B.lmin[0], ly = B.lmax[1] - B.lmin[1], lz = B.lmax[2] - B.lmin[2];
+    const float rx = B.rmax[0] - B.rmin[0], ry = B.rmax[1] - B.rmin[1], rz = B.rmax[2] - B.rmin[2];
+    c = ((double)lx * ly + (double)ly * lz + (double)lz * lx) + ((double)rx * ry + (double)ry * rz + (double)rz * rx);
+  }
+  part[threadIdx.x] = c;
+  __syncthreads();
+  for (int w = BLOCK / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = part[0];
+}
+
 // One wave of the collapse: every frontier entry (binary node b, wide slot w) fills wide node w with
 // b's grandchildren (a child that is a leaf stays as it is), gives every inner grandchild a new
 // wide slot and puts it on the next frontier. Launched level by level until the frontier is empty.

@@ -212,6 +212,14 @@ int mipt_scene_create_opts(const MiptTriangle* tris, size_t n_tris,
                            const MiptSphere* spheres, size_t n_spheres,
                            int device, uint32_t options, MiptScene** out);
 int mipt_scene_has_bvh(MiptScene* scene, uint64_t* n_nodes, double* build_ms);
+/* How the tree was built (no counterpart in the reference). Two binary trees are built over the
+ * Morton-sorted triangles -- one by locally-ordered clustering (neighbours whose joint box has the
+ * smallest surface merge, round by round), one from the bits of the keys (the radix tree) -- and the
+ * one with the lower surface-area cost is collapsed into the four-wide nodes. *clustered = 1 if that
+ * was the clustered tree, *depth = the clustered tree's depth in binary levels (it is also dropped if
+ * deeper than the walk's stack is sized for: 47), *cost_ratio = its cost / the radix tree's. All
+ * nullable; returns 1 / 0 like mipt_scene_has_bvh. Query results do not depend on the choice. */
+int mipt_scene_tree_info(MiptScene* scene, int* clustered, int* depth, float* cost_ratio);
 /* Linear-scan scenes: how many pairs of consecutive coplanar triangles sharing an edge (the two
  * halves of a wall or box face, TestModelH.h:87-160) the candidate filter treats as one unit.
  * Purely an optimisation of the filter; every candidate still goes through the reference's test. */

@@ -77,6 +77,54 @@ def test_tree_equals_literal_scan_on_device(api, O, dtype, name):
     assert redo < n_rays // 100  # the exhaustive traversal is the exception
 
 
+def test_the_tree_with_the_lower_surface_cost_is_kept(api, O, dtype):
+    # two binary trees per scene, clustered and radix: a mesh keeps the clustered one (its boxes are
+    # a seventh smaller in total), evenly scattered small triangles keep the radix tree
+    for name, clustered in (("mesh140k", True), ("config5", False)):
+        tris = scenes(O, dtype)[name]
+        sc = api.Scene(tris() if callable(tris) else tris)
+        got, depth, ratio = sc.tree_info()
+        sc.close()
+        print(f"{name}: clustered={got} depth={depth} cost ratio={ratio:.3f}")
+        assert got == clustered and got == (ratio < 1.0) and 0.5 < ratio < 1.5 and 10 <= depth <= 47
+    small = api.Scene(bigscenes.room(O))
+    assert small.tree_info() is None  # a linear-scan scene
+    small.close()
+
+
+def test_a_clustered_tree_too_deep_for_the_walk_gives_way_to_the_radix_tree(api, O, dtype):
+    # 300 parallel triangles around one point, each 3 % larger than the one before and its box around
+    # all the earlier boxes: joined with any smaller cluster a box stays what it was, so every cluster
+    # chooses the first of its neighbours, only the first two choose each other, and clustering ends
+    # as a chain as deep as the scene is large. The radix tree (depth bounded by the key length) is
+    # kept instead, and the results are the linear scan's.
+    n = 300
+    k = np.arange(n)
+    size = 1.0e-4 * 1.03 ** k
+    c = np.array([0.1, -0.05, 0.2])
+    shape = np.array([[-1.0, -1.0, -1.0], [1.0, 1.0, -1.0], [-1.0, 1.0, 1.0]])  # its box: [-1, 1]^3
+
+    def vert(j):
+        return c + (2e-6 * k)[:, None] + size[:, None] * shape[j]
+
+    color = np.random.default_rng(2).uniform(0.2, 0.9, (n, 3)).astype(np.float32)
+    tris = np.concatenate([bigscenes.room(O), bigscenes._finish(dtype, vert(0), vert(1), vert(2), color, np.zeros(n, dtype=np.uint32))])
+    sc = api.Scene(tris)
+    clustered, depth, _ = sc.tree_info()
+    assert not clustered and depth > 47, (clustered, depth)
+    _, _, closest_bad, any_bad = sc.selfcheck(1 << 18, seed=3)
+    assert (closest_bad, any_bad) == (0, 0) and sc.last_selfcheck_bvh[1] == 0
+    o, d = raygen.interior_rays(1 << 13)
+    aim = c + np.random.default_rng(5).normal(scale=0.03, size=(1 << 12, 3)) - o[: 1 << 12, :3]
+    d[: 1 << 12, :3] = aim / np.linalg.norm(aim, axis=1, keepdims=True)
+    d[: 1 << 12, 3] = 1.0
+    d[: 1 << 12] = (d[: 1 << 12] / np.linalg.norm(d[: 1 << 12].astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    idx, t, pos = sc.closest_hit(o, d)
+    oidx, ot, opos = O.closest_hit(tris, None, o, d)
+    sc.close()
+    assert np.array_equal(idx, oidx) and np.array_equal(bits(t), bits(ot)) and (idx >= 10).sum() > 100
+
+
 def test_threshold_and_small_trees(api, O, dtype):
     # just below the threshold: linear scan; at and just above it: a tree
     soup = np.concatenate([bigscenes.room(O), bigscenes.soup(dtype, 300, seed=9, size=0.2)])
