@@ -213,8 +213,10 @@ struct StageCursor {
 
 // The binary tree by locally-ordered clustering over the sorted triangles (k_ploc_* in mipt_bvh.hpp).
 // On success *root is the root's index in `bin`; *root = -1 (and MIPT_OK) when the tree came out deeper
-// than PLOC_MAX_DEPTH, i.e. deeper than the walk's stack is sized for: the caller builds the radix tree
-// instead. *depth, *rounds: what the clustering did (diagnostics).
+// than PLOC_MAX_DEPTH, i.e. deeper than the walk's stack is sized for, or when the clustering was given up
+// after PLOC_MAX_ROUNDS rounds (10^6 triangles take 58; a scene that needs more merges a pair or two a round
+// and ends as a chain anyway): the caller builds the radix tree instead. *depth (0 if given up), *rounds:
+// what the clustering did (diagnostics).
 static int build_ploc(const Aabb* tri_box, const int* sorted_ids, int n, BvhBin* bin, int* root, int* depth, int* rounds) {
   *root = -1;
   DevBuf cbox0, cbox1, cid0, cid1, nn, keep, pos, counter, tmp;
@@ -236,7 +238,7 @@ static int build_ploc(const Aabb* tri_box, const int* sorted_ids, int n, BvhBin*
   int m = n;
   int round = 0;
   for (; m > 1; ++round) {
-    if (round >= 4096) return fail(MIPT_E_HIP, "tree clustering did not finish in %d rounds (%d clusters left)", round, m);
+    if (round >= PLOC_MAX_ROUNDS) { *depth = 0; *rounds = round; return MIPT_OK; }  // *root stays -1
     hipLaunchKernelGGL(k_ploc_nearest, dim3(grid_for(m)), dim3(BLOCK), 0, nullptr, cb, m, nn.as<int>());
     hipLaunchKernelGGL(k_ploc_merge, dim3(grid_for(m)), dim3(BLOCK), 0, nullptr, cb, ci, nn.as<int>(), m, bin,
                        counter.as<int>(), keep.as<uint32_t>());

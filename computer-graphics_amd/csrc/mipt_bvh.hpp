@@ -242,7 +242,7 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_refit(BvhBin* __restrict__ nodes,
 // of the keys, decide what is grouped, which costs a ray a third fewer nodes on a mesh than the radix
 // tree over the same keys. Depth: every cluster carries the depth of its subtree, and the builder falls
 // back to the radix tree (whose depth is bounded by its key length) if the finished tree is deeper than
-// the walk's stack allows.
+// the walk's stack allows, or if the clustering has not finished after PLOC_MAX_ROUNDS rounds.
 #ifndef MIPT_BVH_PLOC
 #define MIPT_BVH_PLOC 1
 #endif
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_refit(BvhBin* __restrict__ nodes,
 #define MIPT_BVH_PLOC_RADIUS 16
 #endif
 constexpr int PLOC_RADIUS = MIPT_BVH_PLOC_RADIUS;
+constexpr int PLOC_MAX_ROUNDS = 512;
 constexpr int PLOC_MAX_DEPTH = 47;  // binary levels: the walk's stack holds 3 entries for each of 48 four-wide levels
 
 __device__ __forceinline__ float aabb_union_area(const Aabb& a, const Aabb& b) {

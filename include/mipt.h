@@ -217,7 +217,9 @@ int mipt_scene_has_bvh(MiptScene* scene, uint64_t* n_nodes, double* build_ms);
  * smallest surface merge, round by round), one from the bits of the keys (the radix tree) -- and the
  * one with the lower surface-area cost is collapsed into the four-wide nodes. *clustered = 1 if that
  * was the clustered tree, *depth = the clustered tree's depth in binary levels (it is also dropped if
- * deeper than the walk's stack is sized for: 47), *cost_ratio = its cost / the radix tree's. All
+ * deeper than the walk's stack is sized for: 47; 0 = the clustering was given up after 512 rounds, which
+ * only a scene that clusters into a chain needs), *cost_ratio = its cost / the radix tree's (0 if the
+ * clustered tree was dropped before the comparison). All
  * nullable; returns 1 / 0 like mipt_scene_has_bvh. Query results do not depend on the choice. */
 int mipt_scene_tree_info(MiptScene* scene, int* clustered, int* depth, float* cost_ratio);
 /* Linear-scan scenes: how many pairs of consecutive coplanar triangles sharing an edge (the two
