@@ -857,8 +857,17 @@ static void build_scan_units(const MiptTriangle* tris, const std::vector<TriRec>
     }
     size_t k = lo;
     for (const BoxUnit& b : boxes) { memcpy(&units[k], &b, sizeof b); k += 2; }
-    std::stable_sort(axis_pairs.begin(), axis_pairs.end(), [](const ScanUnit& x, const ScanUnit& y) {
-      uint32_t ax, ay; memcpy(&ax, &x.e2z, 4); memcpy(&ay, &y.e2z, 4); return ax < ay; });
+    // a stable insertion sort in place (at most 16 units): std::stable_sort moves the elements through
+    // a temporary buffer that the library allocates without regard for the records' 64-byte alignment
+    {
+      auto key = [](const ScanUnit& x) { uint32_t a; memcpy(&a, &x.e2z, 4); return a; };
+      for (size_t i = 1; i < axis_pairs.size(); ++i) {
+        const ScanUnit u = axis_pairs[i];
+        size_t j = i;
+        for (; j > 0 && key(axis_pairs[j - 1]) > key(u); --j) axis_pairs[j] = axis_pairs[j - 1];
+        axis_pairs[j] = u;
+      }
+    }
     for (const ScanUnit& u : axis_pairs) units[k++] = u;
     for (const ScanUnit& u : pairs) units[k++] = u;
     for (const ScanUnit& u : singles) units[k++] = u;
