@@ -84,3 +84,17 @@ def test_host_demo_matches_python_host(pkg, which, size, frames, spf, mode):
     assert int(kv["samples"]) == frames * spf and int(kv["n_tris"]) == len(tris)
     assert int(kv["screen_sum"]) == int(img.astype(np.uint64).sum())
     assert abs(float(kv["pixel_sum"]) - float(acc.astype(np.float64).sum())) <= 1e-9 * abs(float(acc.sum()))
+
+
+@pytest.mark.gpu
+def test_library_host_code_runs_clean_under_the_host_sanitizers_on_the_gpu():
+    # computer-graphics_amd/host/san_gpu.cpp: the library with AddressSanitizer + UndefinedBehaviorSanitizer on
+    # its host side (the kernels are the shipped ones) driving the GPU through every entry point -- scenes of
+    # all four kinds incl. both binary trees, batches through host and device pointers, renders, listed
+    # paths, frames, the entry point that allocates nothing, several parts on one device, one rank through
+    # RCCL, and ~40 calls with bad arguments. No sanitizer report, every return code as expected.
+    exe = os.path.join(ROOT, "computer-graphics_amd", "host", "san_gpu")
+    assert os.path.exists(exe), "san_gpu is built by __graft_entry__.build()"
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 0 and "gpu host sanitizer run ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
