@@ -860,3 +860,54 @@ def test_full_size_launch_properties(api, O, pkg):
     assert np.isfinite(w).all() and w.sum() > 0
     # two launches of half the samples leave the bits of the one launch
     assert torch.equal(whole.view(torch.int32), halves.view(torch.int32))
+
+
+def test_scenes_used_from_several_host_threads_at_once(api, O, pkg):
+    # the header's threading contract: one scene is for one host thread at a time, different scenes may
+    # be used concurrently. Four threads, each with its own scene (linear scan, linear scan with a
+    # sphere, a tree, the same tree forced to the linear scan), render, query and trace at the same
+    # time, several times over; every result is the one the same calls give when made alone.
+    import threading
+    import bigscenes
+    dtype = pkg.abi.TRIANGLE_DTYPE
+    mesh = bigscenes.mesh_in_room(O, dtype, cells=24, nu=32, nv=16)
+    sphere = api.make_sphere(0.3, [-0.45, 0.7, -0.55, 1], [1, 0, 0])
+    setups = [(O.load_test_model(2), None, {}), (O.load_test_model(0), sphere, {}), (mesh, None, {}), (mesh, None, {"linear_scan": True})]
+    W, H = 72, 56
+    cam, light = api.default_camera(W), api.default_light(True)
+    o, d = raygen.interior_rays(1 << 14)
+    lim = np.full(len(o), 0.7, dtype=np.float32)
+
+    def work(k, scene, rounds):
+        out = []
+        p = api.default_params(W, H, seed=10 + k, fog_sigma_t=0.1 if k % 2 else 0.0)
+        for r in range(rounds):
+            img = scene.render_accumulate(cam, light, p, 16 * r, 16)
+            idx, t, pos = scene.closest_hit(o, d)
+            occ = scene.any_hit(o, d, lim)
+            out.append((bits(img).copy(), idx.copy(), bits(t[idx >= 0]).copy(), occ.copy()))
+        return out
+
+    scenes = [api.Scene(t, sp, **kw) for t, sp, kw in setups]
+    alone = [work(k, sc, 3) for k, sc in enumerate(scenes)]
+    together = [None] * len(scenes)
+    errors = []
+
+    def run(k):
+        try:
+            together[k] = work(k, scenes[k], 3)
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    for _ in range(3):
+        threads = [threading.Thread(target=run, args=(k,)) for k in range(len(scenes))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors
+        for k in range(len(scenes)):
+            for a, b in zip(alone[k], together[k]):
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), k
+    for sc in scenes:
+        sc.close()
