@@ -361,9 +361,9 @@ static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
     if (rc != MIPT_OK) return rc;
     radix = bin_root < 0;
     if (!radix) {
-      // both trees, and the one with the lower surface-area cost is kept: clustering wins on meshes,
-      // the radix tree on evenly scattered small triangles, where splitting space in the middle is
-      // already the best there is
+      // both trees; the clustered one is kept when its surface-area cost is clearly lower (PLOC_KEEP_RATIO):
+      // clustering wins on meshes, the radix tree on evenly scattered small triangles, where splitting
+      // space in the middle is already the best there is
       HIP_TRY(bin_b.alloc((size_t)(n - 1) * sizeof(BvhBin)));
       const int rr = build_radix_tree(keys2.as<unsigned long long>(), ids2.as<int>(), box.as<Aabb>(), n, bin_b.as<BvhBin>());
       if (rr != MIPT_OK) return rr;
@@ -372,7 +372,7 @@ static int build_bvh(MiptScene* s, const std::vector<int>& subset) {
       if (r1 != MIPT_OK) return r1;
       if (r2 != MIPT_OK) return r2;
       s->bvh_cost_ratio = c_radix > 0.0 ? (float)(c_ploc / c_radix) : 0.f;
-      if (!(c_ploc < c_radix)) {
+      if (!(c_ploc < PLOC_KEEP_RATIO * c_radix)) {
         std::swap(bin.p, bin_b.p);
         bin_root = 0;
         s->bvh_radix_tree = true;

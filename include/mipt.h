@@ -215,7 +215,8 @@ int mipt_scene_has_bvh(MiptScene* scene, uint64_t* n_nodes, double* build_ms);
 /* How the tree was built (no counterpart in the reference). Two binary trees are built over the
  * Morton-sorted triangles -- one by locally-ordered clustering (neighbours whose joint box has the
  * smallest surface merge, round by round), one from the bits of the keys (the radix tree) -- and the
- * one with the lower surface-area cost is collapsed into the four-wide nodes. *clustered = 1 if that
+ * clustered one is collapsed into the four-wide nodes if its surface-area cost is below 0.9 of the
+ * radix tree's, else the radix tree. *clustered = 1 if that
  * was the clustered tree, *depth = the clustered tree's depth in binary levels (it is also dropped if
  * deeper than the walk's stack is sized for: 47; 0 = the clustering was given up after 512 rounds, which
  * only a scene that clusters into a chain needs), *cost_ratio = its cost / the radix tree's (0 if the

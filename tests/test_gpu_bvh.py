@@ -79,14 +79,15 @@ def test_tree_equals_literal_scan_on_device(api, O, dtype, name):
 
 def test_the_tree_with_the_lower_surface_cost_is_kept(api, O, dtype):
     # two binary trees per scene, clustered and radix: a mesh keeps the clustered one (its boxes are
-    # a seventh smaller in total), evenly scattered small triangles keep the radix tree
-    for name, clustered in (("mesh140k", True), ("config5", False)):
+    # a seventh smaller in total), evenly scattered small triangles keep the radix tree, and so does
+    # config 4's closed mesh, whose clustered tree is only 9 % cheaper (kept below 0.9)
+    for name, clustered in (("mesh140k", True), ("config5", False), ("config4", False)):
         tris = scenes(O, dtype)[name]
         sc = api.Scene(tris() if callable(tris) else tris)
         got, depth, ratio = sc.tree_info()
         sc.close()
         print(f"{name}: clustered={got} depth={depth} cost ratio={ratio:.3f}")
-        assert got == clustered and got == (ratio < 1.0) and 0.5 < ratio < 1.5 and 10 <= depth <= 47
+        assert got == clustered and got == (ratio < 0.9) and 0.5 < ratio < 1.5 and 10 <= depth <= 47
     small = api.Scene(bigscenes.room(O))
     assert small.tree_info() is None  # a linear-scan scene
     small.close()
